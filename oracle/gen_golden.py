@@ -1,0 +1,415 @@
+"""TEST INFRASTRUCTURE: writes tests/golden/*.npz from the REFERENCE ITSELF (oracle/_ref/libref.so = the
+reference's unmodified C++ compiled with oracle/ref_harness.cpp; `make -C oracle ref` first).  Runs only
+where /root/reference exists.  While generating, every vector is also compared with the C restatement
+(oracle/rt_oracle.c, libm math mode) and any mismatch aborts: the fixtures double as the oracle's pin.
+
+    python oracle/gen_golden.py            # all fixtures (~3 min on 8 cores)
+"""
+import hashlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import orcbind as O  # noqa: E402
+from oracle.refbind import Ref  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+BUILD_KEY = 0x5EED0001
+SEED = 7
+CAM_POS, CAM_LOOK = (0.0, 3.0, -10.0), (0.0, 0.0, 1.0)   # World.cpp:48
+
+
+def bits_equal(a, b):
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    if a.shape != b.shape or a.dtype != b.dtype:
+        return False
+    return a.tobytes() == b.tobytes()
+
+
+def must(name, a, b):
+    if not bits_equal(a, b):
+        raise SystemExit(f"PIN FAILURE: oracle restatement differs from the reference on {name}")
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"  wrote {name}.npz  {os.path.getsize(path) / 1e6:.2f} MB")
+
+
+def special_rays(rng, n, box=8.0):
+    """random rays plus the awkward ones: zero / negative-zero direction components, origins on faces, inf/NaN"""
+    o = rng.uniform(-box, box, (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    k = n // 8
+    d[:k, 0] = 0.0
+    d[k:2 * k, 1] = -0.0
+    d[2 * k:3 * k, 2] = 0.0
+    d[3 * k:3 * k + 8, :2] = 0.0
+    o[:k:2, 0] = 1.0
+    o[k:2 * k:2, 1] = -1.0
+    o[4 * k:4 * k + 4] = 0.0
+    d[4 * k + 4, 0] = np.inf
+    d[4 * k + 5, 1] = np.nan
+    o[4 * k + 6, 2] = np.inf
+    return o, d
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    R = Ref()
+    rng = np.random.default_rng(20260101)
+    t_all = time.time()
+
+    # ---------------------------------------------------------------- assets as the reference decodes them
+    verts = R.load_obj("src/stb_image/tree.obj")
+    tex, tex_fc = R.load_image("src/stb_image/tree_texture.png", 4)
+    sky, sky_fc = R.load_image("src/stb_image/skybox12.png", 3)
+    save("assets",
+         tree_verts8=verts,
+         tree_texture_sha256=np.frombuffer(hashlib.sha256(tex.tobytes()).digest(), np.uint8),
+         tree_texture_shape=np.array(tex.shape), tree_texture_file_channels=np.array(tex_fc),
+         skybox_sha256=np.frombuffer(hashlib.sha256(sky.tobytes()).digest(), np.uint8),
+         skybox_shape=np.array(sky.shape), skybox_file_channels=np.array(sky_fc),
+         tree_texture_probe=tex[::37, ::41].copy(), skybox_probe=sky[::17, ::19].copy())
+
+    # ---------------------------------------------------------------- RNG known answers (DataUtility.h:11-41)
+    keys = np.array([0, 1, 0xDEADBEEF, BUILD_KEY], np.uint32)
+    r31 = np.array([[R.L.ref_rand31(int(k), c) for c in range(16)] for k in keys], np.uint32)
+    skeys = np.array([[R.L.ref_sample_key(SEED, p, s) for s in range(4)] for p in (0, 1, 921599, 2073599)], np.uint32)
+    must("rand31", r31, np.array([[O.lib().orc_rand31(int(k), c) for c in range(16)] for k in keys], np.uint32))
+    must("sample_key", skeys, np.array([[O.lib().orc_sample_key(SEED, p, s) for s in range(4)] for p in (0, 1, 921599, 2073599)], np.uint32))
+    R.L.ref_rng_set(0xDEADBEEF, 0)
+    r01 = np.array([R.L.ref_random01() for _ in range(32)], np.float32)
+    R.L.ref_rng_set(0xDEADBEEF, 0)
+    rud = np.array([R.L.ref_random_unit_distance() for _ in range(32)], np.float32)
+    R.L.ref_rng_set(0xDEADBEEF, 0)
+    sph = np.zeros((16, 3), np.float32)
+    for i in range(16):
+        R.L.ref_unit_sphere_point(sph[i])
+    sph_ctr = R.L.ref_rng_ctr()
+    R.L.ref_rng_set(0xDEADBEEF, 0)
+    cir = np.zeros((16, 2), np.float32)
+    for i in range(16):
+        R.L.ref_unit_circle_point(cir[i])
+    cir_ctr = R.L.ref_rng_ctr()
+    save("rng", keys=keys, rand31=r31, sample_key_seed=np.array(SEED), sample_key_pixels=np.array([0, 1, 921599, 2073599]),
+         sample_keys=skeys, random01=r01, random_unit_distance=rud, sphere_points=sph, sphere_draws=np.array(sph_ctr),
+         circle_points=cir, circle_draws=np.array(cir_ctr))
+
+    # ---------------------------------------------------------------- AABB known answers: the table in Main.cpp:24-46
+    box = np.array([-1, -1, -1, 1, 1, 1], np.float32)
+    kat_o = np.array([[-2, -2, -2], [2, -2, -2], [-2, 2, 2], [2, 2, 2], [2, -2, -2], [2, -2, -2], [-2, 2, 2], [2, 2, 2],
+                      [2, 2, 2], [2, 1, 2], [-2, 2, -2], [-2, 1, -2], [0, 0, 0], [0, 0, 0]], np.float32)
+    kat_d = np.array([[1, 1, 1], [-1, 1, 1], [1, -1, -1], [-1, -1, -1], [1, 1, 1], [-1, -1, -1], [1, -1, 1], [1, 1, 1],
+                      [1, 0, 1], [1, 0, 1], [-1, 0, -1], [-1, 0, -1], [1, 1, 1], [-1, -1, -1]], np.float32)
+    kat_expect = np.array([1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1], np.uint8)   # the "should hit" column of Main.cpp
+    kat_dn = R.normalize(kat_d)                                                  # Main.cpp:19
+    must("normalize", kat_dn, O.normalize(kat_d))
+    kat_got = R.aabb_hit(box, kat_o, kat_dn)
+    if not np.array_equal(kat_got, kat_expect):
+        print("  note: reference DoesRayHit differs from its own commented expectations at", np.nonzero(kat_got != kat_expect)[0])
+    must("aabb kat", kat_got, O.aabb_hit(box, kat_o, kat_dn))
+    ro, rd = special_rays(rng, 4096, 3.0)
+    boxes = np.array([[-1, -1, -1, 1, 1, 1], [0.5, -2, 0.25, 2.5, -1, 3], [1, 1, 1, -1, -1, -1], [0, 0, 0, 0, 0, 0]], np.float32)
+    aabb_out = np.stack([R.aabb_hit(b, ro, rd) for b in boxes])
+    must("aabb random", aabb_out, np.stack([O.aabb_hit(b, ro, rd) for b in boxes]))
+    save("aabb", box=box, kat_o=kat_o, kat_d=kat_d, kat_d_normalized=kat_dn, kat_expect_comment=kat_expect, kat_reference=kat_got,
+         boxes=boxes, rays_o=ro, rays_d=rd, hits=aabb_out)
+
+    # ---------------------------------------------------------------- per-primitive Intersect vectors
+    prim = {}
+    ro, rd = special_rays(rng, 2048, 6.0)
+    FILL = -77.0
+    for name, kind, params in (("sphere", 0, [0.5, -0.25, 1.0, 2.0]), ("sphere_negr", 0, [0.5, -0.25, 1.0, -2.0]),
+                               ("cube", 1, [-1.0, -2.0, -0.5, 2.0, 1.0, 3.0]), ("plane", 4, [0.0]), ("plane_y", 4, [-1.5])):
+        hit, rec = R.intersect_prim(kind, params, ro, rd, FILL)
+        h2, r2 = O.intersect_prim(kind, params, ro, rd, FILL)
+        must(name + " hit", hit, h2)
+        # the sphere's uv goes through atan2f: compare in libm mode only, which intersect_prim's temp scene uses
+        must(name + " rec", rec, r2)
+        prim[name + "_params"] = np.array(params, np.float32)
+        prim[name + "_hit"] = hit
+        prim[name + "_rec"] = rec
+    tri = np.array([[-1.0, 0.2, 0.1, 0.1, 0.2, 0, 0.6, 0.8], [2.0, 0.5, -0.3, 0.9, 0.1, 0, 0.6, 0.8], [0.3, 2.5, 1.0, 0.4, 0.95, 0, 0.6, 0.8]], np.float32)
+    tri_flat = np.array([[-1.0, 0.0, 0.0, 0, 0, 0, 1, 0], [1.0, 0.0, 0.0, 1, 0, 0, 1, 0], [0.0, 0.0, 0.0, 0, 1, 0, 1, 0]], np.float32)  # collinear in y-z
+    to, td = special_rays(rng, 2048, 3.0)
+    td[:1024] = (tri[:, :3].mean(0) + rng.normal(scale=0.7, size=(1024, 3)) - to[:1024]).astype(np.float32)
+    for name, tv, alpha in (("tri", tri, 0), ("tri_alpha", tri, 1), ("tri_degenerate", tri_flat, 0)):
+        hit, rec = R.intersect_tri(tv, alpha, to, td, FILL)
+        h2, r2 = O.intersect_tri(tv, tex if alpha else None, to, td, FILL)
+        must(name + " hit", hit, h2)
+        must(name + " rec", rec, r2)
+        prim[name + "_verts"] = tv
+        prim[name + "_hit"] = hit
+        prim[name + "_rec"] = rec
+    save("prims", rays_o=ro, rays_d=rd, tri_rays_o=to, tri_rays_d=td, fill=np.array(FILL, np.float32), **prim)
+
+    # ---------------------------------------------------------------- default scene: structure
+    w = R.world(BUILD_KEY)
+    cam = R.get_camera(w).ravel().copy()
+    must("camera", cam, O.camera(CAM_POS, CAM_LOOK))
+    s = O.Scene(O.MATH_LIBM)
+    s.default_scene(verts, tex, sky)
+    s.build(BUILD_KEY)
+    top = R.dump_top(w)
+    mesh = R.dump_mesh(w, 2)
+    objs = R.dump_objects(w, 19)
+    inst = R.dump_instance(w, 2)
+    for n, a, b in zip(("boxes", "left", "right", "leaf"), top, s.dump_top()):
+        must("top " + n, a, b)
+    for n, a, b in zip(("boxes", "left", "right", "tris"), mesh, s.dump_mesh(2)):
+        must("mesh " + n, a, b)
+    must("objects", objs, s.dump_objects(19))
+    must("instance", inst, s.dump_instance(2))
+    save("scene_default", build_key=np.array(BUILD_KEY, np.uint32), camera=cam,
+         top_boxes=top[0], top_left=top[1], top_right=top[2], top_leaf_ids=top[3],
+         mesh_boxes=mesh[0], mesh_left=mesh[1], mesh_right=mesh[2], mesh_tris=mesh[3], objects=objs, instance=inst)
+
+    # ---------------------------------------------------------------- default scene: closest-hit queries on arbitrary rays
+    n = 20000
+    o = np.zeros((n, 3), np.float32)
+    o[:] = CAM_POS
+    o[n // 2:] = rng.uniform([-5, 0.1, -12], [45, 9, 16], (n - n // 2, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d[:n // 2, 2] = np.abs(d[:n // 2, 2]) + 1.0
+    d /= np.linalg.norm(d, axis=1, keepdims=True).astype(np.float32)
+    hit, rec = R.trace(w, o, d)
+    h2, r2 = s.trace(o, d)
+    must("trace hit", hit, h2)
+    # uv of plane hits is never written by the reference (Object.cpp:139-149): mask it before comparing
+    m = hit == 18
+    rec_cmp, r2_cmp = rec.copy(), r2.copy()
+    rec_cmp[m, 7:] = 0
+    r2_cmp[m, 7:] = 0
+    must("trace rec", rec_cmp, r2_cmp)
+    keys = rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32)
+    col = R.ray_color(w, o[:4000], d[:4000], 4, keys[:4000])
+    must("ray_color", col, s.ray_color(o[:4000], d[:4000], 4, keys[:4000]))
+    skyd = rng.normal(size=(4096, 3)).astype(np.float32)
+    skyd /= np.linalg.norm(skyd, axis=1, keepdims=True).astype(np.float32)
+    skyc = R.skybox(w, skyd)
+    must("skybox", skyc, s.skybox_lookup(skyd))
+    save("trace_default", rays_o=o, rays_d=d, hit=hit, rec=rec_cmp, keys=keys[:4000], ray_color_bounces=np.array(4), ray_color=col,
+         sky_dirs=skyd, sky_rgb=skyc)
+
+    # ---------------------------------------------------------------- C1: the reference's own constants, whole frame
+    ci, cf = R.constants()
+    W, H, S, B = (int(v) for v in ci)
+    print(f"  C1 frame {W}x{H} S={S} B={B} ...")
+    t0 = time.time()
+    a = R.render(w, W, H, S, B, SEED, threads=8, want=("primary_id", "rgba"))
+    b = s.render(cam, W, H, S, B, SEED, threads=8, want=("primary_id", "rgba"))
+    must("C1 primary_id", a["primary_id"], b["primary_id"])
+    must("C1 rgba", a["rgba"], b["rgba"])
+    crop = (608, 328, 672, 392)
+    ac = R.render(w, W, H, S, B, SEED, rect=crop, want=("radiance", "primary_id", "primary_t", "ray", "rng_draws", "rgba"))
+    bc = s.render(cam, W, H, S, B, SEED, rect=crop, want=("radiance", "primary_id", "primary_t", "ray", "rng_draws", "rgba"))
+    for k in ac:
+        must("C1 crop " + k, ac[k], bc[k])
+    # the reference's own per-pixel function under per-pixel keys, three rows
+    bad, own = R.check_pixel_loop(w, SEED, (0, 357, W, 360))
+    if bad:
+        raise SystemExit("harness sample loop differs from World::CalculateColorForScreenPosition")
+    must("pixel keyed", own, s.render_pixel_keyed(cam, W, H, S, B, SEED, (0, 357, W, 360)))
+    save("frame_c1", cfg=np.array([W, H, S, B]), cfg_f=cf, seed=np.array(SEED), rgba=a["rgba"], primary_id=a["primary_id"].astype(np.int8),
+         crop=np.array(crop), crop_radiance=ac["radiance"], crop_primary_t=ac["primary_t"], crop_ray=ac["ray"], crop_rng_draws=ac["rng_draws"],
+         pixel_keyed_rows=np.array([357, 360]), pixel_keyed_rgba=own)
+    print(f"    {time.time() - t0:.1f}s")
+
+    # the reference's own scheduler (FrameManager) vs the restated scheduler order
+    secs, fm_rgba = R.framemanager_frame(BUILD_KEY)
+    must("FrameManager frame", fm_rgba, s.render_framemanager(cam, W, H, S, B))
+    print(f"  FrameManager frame: {secs:.2f}s, identical to the restated scheduler")
+    save("frame_c1_framemanager", rgba_sha256=np.frombuffer(hashlib.sha256(fm_rgba.tobytes()).digest(), np.uint8),
+         rows=fm_rgba[::90].copy(), seconds=np.array(secs))
+
+    # ---------------------------------------------------------------- C2: 1920x1080, 64 spp, 8 bounces
+    W2, H2, S2, B2 = 1920, 1080, 8, 8
+    print("  C2 crops and thumbnail ...")
+    t0 = time.time()
+    a = R.render(w, W2, H2, 1, B2, SEED, threads=8, want=("primary_id", "primary_t"))      # sample (0,0) of every pixel
+    b = s.render(cam, W2, H2, 1, B2, SEED, threads=8, want=("primary_id", "primary_t"))
+    must("C2 s0 id", a["primary_id"], b["primary_id"])
+    must("C2 s0 t", a["primary_t"], b["primary_t"])
+    crops = [(928, 508, 992, 540), (1200, 600, 1264, 632), (300, 700, 364, 732)]
+    c2 = {}
+    for i, cr in enumerate(crops):
+        ac = R.render(w, W2, H2, S2, B2, SEED, rect=cr, threads=8, want=("radiance", "primary_id", "primary_t", "rng_draws", "rgba"))
+        bc = s.render(cam, W2, H2, S2, B2, SEED, rect=cr, threads=8, want=("radiance", "primary_id", "primary_t", "rng_draws", "rgba"))
+        for k in ac:
+            must(f"C2 crop{i} {k}", ac[k], bc[k])
+        c2[f"crop{i}"] = np.array(cr)
+        c2[f"crop{i}_radiance"] = ac["radiance"]
+        c2[f"crop{i}_primary_id"] = ac["primary_id"].astype(np.int8)
+        c2[f"crop{i}_primary_t"] = ac["primary_t"]
+        c2[f"crop{i}_rng_draws"] = ac["rng_draws"].astype(np.uint16)
+        c2[f"crop{i}_rgba"] = ac["rgba"]
+    Wt, Ht = 256, 144
+    at = R.render(w, Wt, Ht, S2, B2, SEED, threads=8, want=("primary_id", "rgba"))
+    bt = s.render(cam, Wt, Ht, S2, B2, SEED, threads=8, want=("primary_id", "rgba"))
+    must("C2 thumb id", at["primary_id"], bt["primary_id"])
+    must("C2 thumb rgba", at["rgba"], bt["rgba"])
+    save("frame_c2", cfg=np.array([W2, H2, S2, B2]), seed=np.array(SEED), s0_primary_id=a["primary_id"].astype(np.int8).reshape(H2, W2),
+         s0_primary_t_rows=a["primary_t"].reshape(H2, W2)[::8].copy(), thumb_cfg=np.array([Wt, Ht, S2, B2]),
+         thumb_primary_id=at["primary_id"].astype(np.int8), thumb_rgba=at["rgba"], **c2)
+    print(f"    {time.time() - t0:.1f}s")
+
+    # ---------------------------------------------------------------- C5: scripted camera path (App.cpp:98,114-137)
+    cams = np.zeros((240, 12), np.float32)
+    ocam = O.camera(CAM_POS, CAM_LOOK)
+    for f in range(240):
+        R.L.ref_world_camera_input(w, 3.0, 1.0, int(f < 120), 0, 0, int(f >= 120))
+        ocam = O.camera_input(ocam, 3.0, 1.0, w=int(f < 120), d=int(f >= 120))
+        cams[f] = R.get_camera(w).ravel()
+        must(f"camera path frame {f}", cams[f], ocam)
+    Wm, Hm = 480, 270
+    am = R.render(w, Wm, Hm, 3, 3, SEED, threads=8, want=("primary_id", "rgba"))
+    bm = s.render(cams[239], Wm, Hm, 3, 3, SEED, threads=8, want=("primary_id", "rgba"))
+    must("C5 last frame id", am["primary_id"], bm["primary_id"])
+    must("C5 last frame rgba", am["rgba"], bm["rgba"])
+    save("camera_path", cams=cams, last_cfg=np.array([Wm, Hm, 3, 3]), last_primary_id=am["primary_id"].astype(np.int8), last_rgba=am["rgba"])
+    R.set_camera(w, CAM_POS, CAM_LOOK)
+
+    # ---------------------------------------------------------------- custom scenes through the reference's own object types
+    # (a) small mixed scene: every material and texture kind, inverted-box spheres, nested boxes, two planes
+    tex_t = [[0, .8, .2, .3, 0, 0, 0], [1, .9, .9, .9, .1, .1, .6], [0, .7, .7, .2, 0, 0, 0], [2, 0, 0, 0, 0, 0, 0], [1, 1, 1, 1, .2, .6, .3]]
+    mat_t = [[1, 0, 0, 0, 0], [2, 1, 0, 0, 0], [3, 2, 0, 0, 0], [4, -1, 4, 3, 2], [1, 3, 0, 0, 0], [2, 4, 0, 0, 0], [0, -1, 0, 0, 0], [1, 1, 0, 0, 0]]
+    n_obj = 40
+    obj_t = np.zeros((n_obj, 10), np.float32)
+    for i in range(n_obj):
+        c = rng.uniform([-8, 0.5, -2], [8, 6, 14], 3)
+        if i % 2 == 0:
+            r = rng.uniform(0.3, 1.5) * (-1 if i % 10 == 4 else 1)
+            obj_t[i, :5] = [0, *c, r]
+        elif i % 4 == 1:
+            h = rng.uniform(0.3, 1.2, 3)
+            obj_t[i, :7] = [1, *(c - h), *(c + h)]
+        else:
+            obj_t[i, :5] = [2, *c, rng.uniform(0.3, 1.2)]
+        obj_t[i, 9] = [0, 1, 2, 3, 0, 7, 6, 1][i % 8]
+    obj_t[7] = [3, 6.0, 1, 35.0, -3.0, 2.0, 6.0, 1.0, 0, 4]    # tree: size 6, Y rotation 35 deg, moved
+    obj_t[13] = [3, 4.0, 2, -20.0, 0, 0, 0, 0.0, 0, 4]         # tree: size 4, Z rotation, not moved
+    plane_t = [[0.0, 5], [-3.0, 0]]
+    R.set_custom(w, BUILD_KEY + 1, tex_t, mat_t, obj_t, plane_t)
+    s2 = O.Scene(O.MATH_LIBM)
+    s2.skybox(sky)
+    tx = []
+    for t in tex_t:
+        tx.append(s2.texture_color(t[1:4]) if t[0] == 0 else (s2.texture_checker(t[1:4], t[4:7]) if t[0] == 1 else s2.texture_image(tex)))
+    mt = [s2.material(int(m[0]), tx[int(m[1])] if m[1] >= 0 else -1, m[2:5]) for m in mat_t]
+    for row in obj_t:
+        k = int(row[0])
+        m = mt[int(row[9])]
+        if k == 0:
+            s2.sphere(row[1:4], float(row[4]), m)
+        elif k == 1:
+            s2.cube_minmax(row[1:4], row[4:7], m)
+        elif k == 2:
+            s2.cube_center(row[1:4], float(row[4]), m)
+        else:
+            s2.mesh(verts, float(row[1]), m, int(row[2]), float(row[3]), row[4:7] if row[7] != 0 else None)
+    for p in plane_t:
+        s2.plane(p[0], mt[int(p[1])])
+    s2.build(BUILD_KEY + 1)
+    for n_, a_, b_ in zip(("boxes", "left", "right", "leaf"), R.dump_top(w), s2.dump_top()):
+        must("custom top " + n_, a_, b_)
+    cam2 = O.camera((0.5, 4.0, -9.0), (0.05, -0.15, 1.0))
+    R.set_camera(w, (0.5, 4.0, -9.0), (0.05, -0.15, 1.0))
+    Wc, Hc = 320, 180
+    ac = R.render(w, Wc, Hc, 2, 6, SEED + 1, threads=8, want=("radiance", "primary_id", "primary_t", "rgba"))
+    bc = s2.render(cam2, Wc, Hc, 2, 6, SEED + 1, threads=8, want=("radiance", "primary_id", "primary_t", "rgba"))
+    for k in ac:
+        must("custom " + k, ac[k], bc[k])
+    save("scene_custom", build_key=np.array(BUILD_KEY + 1, np.uint32), tex=np.array(tex_t, np.float32), mat=np.array(mat_t, np.float32),
+         obj=obj_t, plane=np.array(plane_t, np.float32), cam_pos=np.array((0.5, 4.0, -9.0), np.float32), cam_look=np.array((0.05, -0.15, 1.0), np.float32),
+         cfg=np.array([Wc, Hc, 2, 6]), seed=np.array(SEED + 1), primary_id=ac["primary_id"].astype(np.int8), primary_t=ac["primary_t"],
+         radiance=ac["radiance"].astype(np.float32), rgba=ac["rgba"])
+
+    # (b) a scaled-down C3: spheres and boxes from one PCG32 stream, metal plane, skybox
+    n3 = 3000
+    obj3, tex3, mat3 = synthetic_scene(n3)
+    R.set_custom(w, BUILD_KEY + 2, tex3, mat3, obj3, [[0.0, len(mat3) - 1]])
+    s3 = O.Scene(O.MATH_LIBM)
+    s3.skybox(sky)
+    tx = [s3.texture_color(t[1:4]) if t[0] == 0 else s3.texture_checker(t[1:4], t[4:7]) for t in tex3]
+    mt = [s3.material(int(m[0]), tx[int(m[1])], m[2:5]) for m in mat3]
+    for row in obj3:
+        if int(row[0]) == 0:
+            s3.sphere(row[1:4], float(row[4]), mt[int(row[9])])
+        else:
+            s3.cube_center(row[1:4], float(row[4]), mt[int(row[9])])
+    s3.plane(0.0, mt[-1])
+    s3.build(BUILD_KEY + 2)
+    top3 = R.dump_top(w)
+    for n_, a_, b_ in zip(("boxes", "left", "right", "leaf"), top3, s3.dump_top()):
+        must("synthetic top " + n_, a_, b_)
+    cam3 = O.camera((0.0, 20.0, -150.0), (0.0, 0.0, 1.0))
+    R.set_camera(w, (0.0, 20.0, -150.0), (0.0, 0.0, 1.0))
+    a3 = R.render(w, 384, 216, 2, 8, SEED + 2, threads=8, want=("primary_id", "primary_t", "rgba"))
+    b3 = s3.render(cam3, 384, 216, 2, 8, SEED + 2, threads=8, want=("primary_id", "primary_t", "rgba"))
+    for k in a3:
+        must("synthetic " + k, a3[k], b3[k])
+    save("scene_synthetic", n=np.array(n3), build_key=np.array(BUILD_KEY + 2, np.uint32), cfg=np.array([384, 216, 2, 8]), seed=np.array(SEED + 2),
+         top_boxes_sha256=np.frombuffer(hashlib.sha256(top3[0].tobytes()).digest(), np.uint8),
+         top_left=top3[1], top_right=top3[2], top_leaf_ids=top3[3],
+         primary_id=a3["primary_id"].astype(np.int16), primary_t_rows=a3["primary_t"].reshape(216, 384, 4)[::6].copy(), rgba=a3["rgba"])
+    R.free(w)
+    print(f"all fixtures written and the oracle restatement matched the reference on every one ({time.time() - t_all:.0f}s)")
+
+
+# PCG32 (O'Neill, pcg-random.org minimal C implementation, XSH-RR 64/32) — the stream the synthetic scene is drawn from
+class PCG32:
+    def __init__(self, seed=0x853C49E6748FEA9B, inc=0xDA3E39CB94B95BDB):
+        self.state, self.inc = 0, (inc << 1 | 1) & (2**64 - 1)
+        self.next()
+        self.state = (self.state + seed) & (2**64 - 1)
+        self.next()
+
+    def next(self):
+        old = self.state
+        self.state = (old * 6364136223846793005 + self.inc) & (2**64 - 1)
+        xs = (((old >> 18) ^ old) >> 27) & 0xFFFFFFFF
+        rot = old >> 59
+        return ((xs >> rot) | (xs << ((-rot) & 31))) & 0xFFFFFFFF
+
+    def u01(self):
+        return np.float32((self.next() >> 8) / 16777216.0)
+
+
+def synthetic_scene(n, seed=0x853C49E6748FEA9B):
+    """i even -> sphere, odd -> axis-aligned cube(centre, half); centre uniform in [-100,100]x[1,41]x[-100,100],
+    size uniform [0.2,1.0]; material by i mod 4: 0,1 diffuse colour, 2 metal colour, 3 diffuse checker.
+    Returns (obj rows, tex rows, mat rows) in the custom-scene table format; the last material is the metal
+    checker of the default plane."""
+    g = PCG32(seed)
+    obj = np.zeros((n, 10), np.float32)
+    tex, mat = [], []
+    f = np.float32
+    for i in range(n):
+        cx = f(-100) + f(200) * g.u01()
+        cy = f(1) + f(40) * g.u01()
+        cz = f(-100) + f(200) * g.u01()
+        size = f(0.2) + f(0.8) * g.u01()
+        col = [g.u01(), g.u01(), g.u01()]
+        obj[i, :5] = [0 if i % 2 == 0 else 2, cx, cy, cz, size]
+        m = i % 4
+        if m == 3:
+            tex.append([1, *col, 1, 1, 1])
+        else:
+            tex.append([0, *col, 0, 0, 0])
+        mat.append([2 if m == 2 else 1, len(tex) - 1, 0, 0, 0])
+        obj[i, 9] = len(mat) - 1
+    tex.append([1, 1, 1, 1, 0.2, 0.6, 0.3])
+    mat.append([2, len(tex) - 1, 0, 0, 0])
+    return obj, np.array(tex, np.float32), np.array(mat, np.float32)
+
+
+if __name__ == "__main__":
+    main()
