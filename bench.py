@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Headline benchmark: whole-job Mrays/s of the per-pixel path on N MI355X (BASELINE.json `metric`).
+
+A step = one frame of the workload: generate -> (intersect -> shade -> compact) x (bounces+1) -> resolve, with the frame
+cut into image tiles across the N ranks and the tiles gathered to rank 0 over RCCL.  A ray = one closest-hit query
+(one World::GetRayColor invocation of the reference).  Scene, camera and queues are resident in HBM before the timed
+region; nothing is read from the host inside it.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c1|c3] [--no-cpu-baseline]
+    N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BUILD_KEY = 0x5EED0001
+SEED = 7
+CAM_DEFAULT = ((0.0, 3.0, -10.0), (0.0, 0.0, 1.0))          # World.cpp:48
+WORKLOADS = {
+    # name: (description, W, H, S, B)
+    "c1": ("default scene 1280x720, 9 spp, 3 bounces (the reference's Constants.h)", 1280, 720, 3, 3),
+    "c2": ("default scene 1920x1080, 64 spp, 8 bounces", 1920, 1080, 8, 8),
+    "c3": ("synthetic 100k sphere/box scene 3840x2160, 256 spp, 8 bounces", 3840, 2160, 16, 8),
+}
+# FLOPs the reference algorithm spends per counted event (sqrt and divide count 1, compares and libm calls excluded)
+FLOP_WEIGHTS = {"aabb": 16, "sph_test": 17, "sph_hit": 25, "cube_test": 12, "cube_hit": 21, "plane_test": 3, "plane_hit": 6,
+                "tri_test": 52, "tri_uv": 64, "inst_enter": 21, "inst_hit": 21, "samples": 45, "shade": 30}
+# bytes the reference algorithm touches per counted event with the SoA scene layout: 32 B per node visit, 16 B per sphere,
+# 24 B per cube, 36 B per triangle (+36 B on the uv path, +1 texel), 96 B of ray state per ray, 16 B hit record per ray
+BYTE_WEIGHTS = {"aabb": 32, "sph_test": 16, "cube_test": 24, "tri_test": 36, "tri_uv": 40, "rays": 112}
+PEAK_FP32_TFLOPS = 157.3     # MI355X vector FP32 (packed FMA); unfused, unpacked code tops out at 1/4 of it
+PEAK_HBM_GBS = 8000.0
+# measured by the oracle's counters on the C2 workload; used when the CPU leg is skipped
+FALLBACK_FLOP_PER_RAY = {"c1": 640.0, "c2": 640.0, "c3": 1500.0}
+FALLBACK_BYTE_PER_RAY = {"c1": 1100.0, "c2": 1100.0, "c3": 2500.0}
+
+
+def build_scene(rt, workload):
+    if workload in ("c1", "c2"):
+        return rt.default_scene(BUILD_KEY), rt.camera_look(*CAM_DEFAULT)
+    from raytracer_amd.synthetic import synthetic_scene
+    return synthetic_scene(rt, 100000, BUILD_KEY + 2), rt.camera_look((0.0, 20.0, -150.0), (0.0, 0.0, 1.0))
+
+
+def cpu_baseline(workload, W, H, S, B, threads):
+    """the CPU restatement of the reference (oracle/, libm math like the reference) on a bounded sample of the workload:
+    horizontal strips spread over the frame, every sample and bounce of their pixels"""
+    from oracle import orcbind as O
+    import raytracer_amd as rt
+    E = rt.engine
+    asset = os.path.join(E.ASSET_DIR, "src", "stb_image")
+    sky, _ = E.load_png(os.path.join(asset, "skybox12.png"), 3)
+    s = O.Scene(O.MATH_LIBM)
+    if workload in ("c1", "c2"):
+        verts = E.load_obj(os.path.join(asset, "tree.obj"))
+        tex, _ = E.load_png(os.path.join(asset, "tree_texture.png"), 4)
+        s.default_scene(verts, tex, sky)
+        s.build(BUILD_KEY)
+        cam = O.camera(*CAM_DEFAULT)
+    else:
+        from raytracer_amd.synthetic import synthetic_tables, build_from_tables
+        obj, tex_t, mat_t = synthetic_tables(100000)
+        build_from_tables(s, tex_t, mat_t, obj, [[0.0, len(mat_t) - 1]], sky, BUILD_KEY + 2)
+        cam = O.camera((0.0, 20.0, -150.0), (0.0, 0.0, 1.0))
+    n_strips, rows = {"c1": (12, 8), "c2": (17, 4), "c3": (4, 1)}[workload]
+    s.counters(reset=True)
+    t0 = time.perf_counter()
+    px = 0
+    for k in range(n_strips):
+        y0 = int((k + 0.5) * H / n_strips)
+        x1 = W if workload != "c3" else W // 16
+        s.render(cam, W, H, S, B, SEED, rect=(0, y0, x1, min(H, y0 + rows)), threads=threads, want=("rgba",))
+        px += x1 * (min(H, y0 + rows) - y0)
+    dt = time.perf_counter() - t0
+    c = s.counters()
+    flops = sum(FLOP_WEIGHTS[k] * c[k] for k in FLOP_WEIGHTS)
+    nbytes = sum(BYTE_WEIGHTS[k] * c[k] for k in BYTE_WEIGHTS)
+    return {"value": c["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"{n_strips} strips x {rows} rows = {px} pixels of the {W}x{H} frame, all {S * S} spp and {B} bounces, "
+                      f"{c['rays']} rays in {dt:.1f} s; contiguous pixel ranges per thread as FrameManager.cpp:80-82",
+            "flop_per_ray": flops / c["rays"], "byte_per_ray": nbytes / c["rays"], "rays_per_sample": c["rays"] / c["samples"]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--batch-paths", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import raytracer_amd as rt
+    from raytracer_amd.distributed import TileRenderer
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run --nproc-per-node N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP engine is the only compute path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    desc, W, H, S, B = WORKLOADS[args.workload]
+    scene, cam = build_scene(rt, args.workload)
+    eng = rt.Engine(rt.default_config(width=W, height=H, samples_per_axis=S, bounces=B, device=local_rank,
+                                      max_batch_paths=args.batch_paths))
+    eng.set_scene(scene)
+    eng.set_camera(cam)
+    tr = TileRenderer(eng, device, rank, world)
+
+    def barrier():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        tr.render_frame(SEED)
+    barrier()
+    eng.time_kernels(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tr.render_frame(SEED)
+    barrier()
+    dt = time.perf_counter() - t0
+    kern_ms, kern_launches = eng.kernel_times()
+    eng.time_kernels(False)
+    st = eng.stats()                       # this rank's share of one frame (every step renders the same frame)
+
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    counts = torch.tensor([st["rays"], st["paths"]], dtype=torch.float64, device=device)
+    kt = torch.tensor([kern_ms], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+        dist.all_reduce(kt, op=dist.ReduceOp.MAX)
+    dt = float(t[0])
+    rays_frame, paths_frame = float(counts[0]), float(counts[1])
+    if rank == 0:
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            threads = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))
+            cpu = cpu_baseline(args.workload, W, H, S, B, threads)
+        flop_per_ray = cpu["flop_per_ray"] if cpu else FALLBACK_FLOP_PER_RAY[args.workload]
+        byte_per_ray = cpu["byte_per_ray"] if cpu else FALLBACK_BYTE_PER_RAY[args.workload]
+        value = rays_frame * args.steps / dt / 1e6
+        # dominant kernel = the bounce kernel (intersect + shade + compact); its launches of one rank, timed with HIP events
+        kern_s = float(kt[0]) / 1e3
+        rays_rank0 = st["rays"] * args.steps
+        ach_tflops = flop_per_ray * rays_rank0 / kern_s / 1e12 if kern_s > 0 else None
+        ach_gbs = byte_per_ray * rays_rank0 / kern_s / 1e9 if kern_s > 0 else None
+        out = {
+            "metric": "Mrays/s", "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc, "width": W, "height": H, "spp": S * S, "bounces": B, "rays_per_frame": rays_frame,
+                       "paths_per_frame": paths_frame, "parallelism": f"tiles{world}", "batch_paths": eng.cfg.max_batch_paths},
+            "ms_per_frame": dt / args.steps * 1e3,
+            "roofline": {"bound": "valu", "achieved": ach_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": (ach_tflops / PEAK_FP32_TFLOPS) if ach_tflops else None, "traffic": None,
+                         "kernel": "bounce_kernel", "launches": kern_launches,
+                         "avg_launch_ms": (float(kt[0]) / kern_launches) if kern_launches else None,
+                         "flop_per_ray": flop_per_ray, "rays_per_launch": rays_rank0 / kern_launches if kern_launches else None},
+            "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                             "frac": (ach_gbs / PEAK_HBM_GBS) if ach_gbs else None, "byte_per_ray": byte_per_ray},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

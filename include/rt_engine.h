@@ -1,0 +1,170 @@
+/* rt_engine.h — C ABI of the MI355X renderer for the RaskiTech/Raytracer per-pixel path.
+ *
+ * The reference has no plugin or FFI layer: its seam is the C++ class FrameManager
+ * (Raytracer/src/FrameManager.h:12-37) with World (World.h:12-32) and Camera (DataUtility.h:136-154)
+ * behind it.  The functions below are what a binding for that seam calls; the C++ adapter in
+ * raytracer_amd/csrc/compat/ (FrameManager / World / Camera with the reference's signatures) and the Python
+ * binding raytracer_amd/engine.py are both written on top of them.  All citations are relative to
+ * /root/reference/Raytracer/src.
+ *
+ * Conventions: every function returns RT_OK (0) or a negative RT_E_* code; rt_last_error() gives the message
+ * of the last failure on the calling thread.  No exceptions cross this boundary.  An engine or a scene is
+ * owned by one thread at a time.  Pointers are host pointers unless the name starts with d_.
+ */
+#ifndef RT_ENGINE_H
+#define RT_ENGINE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RT_OK 0
+#define RT_E_INVALID (-1)   /* bad argument / object in the wrong state */
+#define RT_E_DEVICE (-2)    /* HIP runtime error */
+#define RT_E_IO (-3)        /* asset could not be read or decoded */
+#define RT_E_NOMEM (-4)
+
+/* MaterialType (DataUtility.h:109-111) and the Texture subclasses (DataUtility.h:75-107) */
+enum { RT_MAT_NONE = 0, RT_MAT_DIFFUSE = 1, RT_MAT_METAL = 2, RT_MAT_ISOTROPIC = 3, RT_MAT_LIGHT = 4 };
+enum { RT_TEX_COLOR = 0, RT_TEX_CHECKER = 1, RT_TEX_IMAGE = 2 };
+
+typedef struct rt_scene rt_scene;     /* host-side scene under construction / flattened */
+typedef struct rt_engine rt_engine;   /* one GPU: device copies of a scene, ray queues, frame buffer */
+
+const char* rt_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Quality settings: the QUALITY and PROGRAM blocks of Constants.h:4-17, made run-time values.
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct rt_config {
+    int32_t width, height;           /* WINDOW_WIDTH, WINDOW_HEIGHT            (Constants.h:4-5)   */
+    int32_t samples_per_axis;        /* SAMPLES_PER_PIXEL_AXIS                  (Constants.h:17)    */
+    int32_t bounces;                 /* LIGHT_BOUNCE_AMOUNT                     (Constants.h:16)    */
+    float fov;                       /* FIELD_OF_VIEW                           (Constants.h:12)    */
+    float skybox_brightness;         /* SKYBOX_BRIGHTNESS                       (Constants.h:13)    */
+    float dof_intensity;             /* DEPTH_OF_FIELD_INTENSITY                (Constants.h:14)    */
+    float focus_distance;            /* FOCUS_DISTANCE                          (Constants.h:15)    */
+    int32_t device;                  /* HIP device ordinal                                           */
+    int32_t max_batch_paths;         /* ray-queue capacity in paths (pixel samples) per batch; 0 = default */
+    int32_t tile_w, tile_h;          /* image-space tile used to split a frame across GPUs; 0 = 64      */
+    int32_t flags;                   /* RT_FLAG_* */
+} rt_config;
+#define RT_FLAG_COUNT_STATS 1        /* count rays / bounces on the device (rt_get_stats) */
+void rt_config_defaults(rt_config* cfg);   /* the values of Constants.h:4-17 */
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Scene construction — replaces the object graph built in World.cpp:15-45 and the constructors of Object.h.
+ * Objects get stable ids in creation order (BVH'd objects first as added, planes continue the numbering).
+ * ------------------------------------------------------------------------------------------------------- */
+int rt_scene_create(rt_scene** out);
+void rt_scene_destroy(rt_scene* s);
+/* Texture::CreateColored / CreateCheckered / CreateFromImage (DataUtility.h:70-72).  Image data: RGBA8, rows as
+ * stb_image returns them after stbi_set_flip_vertically_on_load(true) (DataUtility.cpp:99-102). Return texture id. */
+int rt_scene_add_texture_color(rt_scene* s, const float rgb[3]);
+int rt_scene_add_texture_checker(rt_scene* s, const float rgb1[3], const float rgb2[3]);
+int rt_scene_add_texture_image(rt_scene* s, const uint8_t* rgba, int w, int h);
+int rt_scene_add_texture_file(rt_scene* s, const char* png_path);     /* decodes a PNG itself, flipped, forced RGBA */
+/* Material::Create* (DataUtility.h:114-117). Returns material id. */
+int rt_scene_add_material(rt_scene* s, int type, int texture, const float emit[3]);
+/* Sphere (Object.h:19), AxisAlignedCube (Object.h:29-30), YPlane (Object.h:40). Return object id. */
+int rt_scene_add_sphere(rt_scene* s, const float center[3], float radius, int material);
+int rt_scene_add_cube_center(rt_scene* s, const float center[3], float half, int material);
+int rt_scene_add_cube_minmax(rt_scene* s, const float mn[3], const float mx[3], int material);
+int rt_scene_add_plane(rt_scene* s, float y, int material);
+/* ApplyMovement(offset, ApplyX/Y/ZRotation(degrees, PolygonMesh(obj, size, material))) (World.cpp:26, Object.h:93-156).
+ * verts8: n_tri*3 vertices of (position3, texcoord2, normal3) as LoadOBJ yields them (Object.cpp:349-435).
+ * rot_axis: 0/1/2 = X/Y/Z, -1 = no rotation wrapper.  has_move 0 = no movement wrapper. */
+int rt_scene_add_mesh(rt_scene* s, const float* verts8, int n_tri, float size, int material,
+                      int rot_axis, float degrees, int has_move, const float offset[3]);
+int rt_scene_add_mesh_file(rt_scene* s, const char* obj_path, float size, int material,
+                           int rot_axis, float degrees, int has_move, const float offset[3]);
+/* Skybox (DataUtility.cpp:17-28): RGB8, flipped rows. */
+int rt_scene_set_skybox(rt_scene* s, const uint8_t* rgb, int w, int h);
+int rt_scene_set_skybox_file(rt_scene* s, const char* png_path);
+/* The scene of World.cpp:15-32 with assets from asset_dir ("<asset_dir>/src/stb_image/tree.obj" ...). */
+int rt_scene_add_default_objects(rt_scene* s, const char* asset_dir, float time);
+/* BVH_Node::BVH_Node (Object.cpp:181-225) for every mesh and for the object list, in the reference's order, with the
+ * keyed counter RNG standing in for std::rand; then flattening into the device layout.  Call once. */
+int rt_scene_build(rt_scene* s, uint32_t build_key);
+
+/* Introspection used by the parity tests (same shapes as the oracle's dumps): preorder inner nodes, child >= 0 =
+ * inner index, child < 0 = ~leaf slot in first-visit order. */
+int rt_scene_dump_top(const rt_scene* s, int max_nodes, float* boxes6, int32_t* left, int32_t* right,
+                      int32_t* leaf_ids, int32_t* n_leaves);
+int rt_scene_dump_mesh(const rt_scene* s, int object_id, int max_nodes, float* boxes6, int32_t* left, int32_t* right,
+                       int max_tris, float* tris24, int32_t* n_tris);
+int rt_scene_dump_objects(const rt_scene* s, int max_obj, float* out20);
+int rt_scene_dump_instance(const rt_scene* s, int object_id, float* out17);
+/* sizes of the flattened scene: entries, triangles, instances, objects, planes, texel bytes, total device bytes */
+int rt_scene_flat_info(const rt_scene* s, int64_t out7[7]);
+
+/* Host asset decoders on their own (Object.cpp:349-435 LoadOBJ; DataUtility.cpp:17-28,98-109 image loads). */
+int rt_load_obj(const char* path, int max_verts, float* verts8);              /* returns vertex count or <0 */
+int rt_load_png(const char* path, int channels, int flip, int64_t max_bytes, uint8_t* out, int32_t* w, int32_t* h,
+                int32_t* file_channels);                                      /* returns byte count or <0 */
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Camera (DataUtility.h:136-154, DataUtility.cpp:10-15) and the front end's input mapping (App.cpp:98,114-137).
+ * cam12 = pos, forward, u, v.
+ * ------------------------------------------------------------------------------------------------------- */
+void rt_camera_look(const float pos[3], const float look[3], float cam12[12]);
+void rt_camera_input(float cam12[12], float xrel, float yrel, int key_w, int key_a, int key_s, int key_d);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Engine — replaces FrameManager::StartNewFrame/ThreadWork (FrameManager.cpp:7-30,78-122) and everything
+ * World::CalculateColorForScreenPosition calls (World.cpp:68-193).
+ * ------------------------------------------------------------------------------------------------------- */
+int rt_engine_create(const rt_config* cfg, rt_engine** out);
+void rt_engine_destroy(rt_engine* e);
+int rt_engine_set_scene(rt_engine* e, const rt_scene* s);              /* uploads the flattened scene */
+int rt_engine_set_camera(rt_engine* e, const float cam12[12]);
+int rt_engine_get_config(const rt_engine* e, rt_config* out);
+
+/* Render this rank's share of a frame, asynchronously on `stream` (a hipStream_t, NULL = the engine's own stream).
+ * frame_seed keys the per-(pixel, sample) RNG streams.  The image is cut into tile_w x tile_h tiles numbered row-major;
+ * rank r of n renders tiles r, r+n, r+2n, ...
+ *   n_ranks == 1: d_rgba (device pointer, NULL = the engine's own frame buffer) receives the whole frame:
+ *                 width*height*4 bytes, [A=255,B,G,R] per pixel, row-major, top row first (FrameManager.cpp:89-94).
+ *   n_ranks  > 1: d_rgba receives rt_engine_tile_bytes() bytes: this rank's tiles packed one after another, each
+ *                 tile_h x tile_w x 4; slots beyond the rank's tile count stay zero. */
+int rt_engine_render(rt_engine* e, uint32_t frame_seed, int rank, int n_ranks, uint8_t* d_rgba, void* stream);
+int64_t rt_engine_tile_bytes(const rt_engine* e, int n_ranks);         /* per-rank packed size, equal on all ranks */
+/* Restrict following renders to the pixel rectangle [x0,x1) x [y0,y1) of the frame (tiles are then cut from the window;
+ * pixels outside keep their previous bytes).  Pixels keep their frame coordinates, so rays and RNG keys do not change —
+ * the counterpart of calling CalculateColorForScreenPosition (World.cpp:68) for a sub-range of pixels. */
+int rt_engine_set_window(rt_engine* e, int x0, int y0, int x1, int y1);
+/* Scatter gathered tiles (n_ranks packed buffers back to back, as an all-gather / gather leaves them) into a frame. */
+int rt_engine_assemble(rt_engine* e, const uint8_t* d_gathered, int n_ranks, uint8_t* d_rgba, void* stream);
+int rt_engine_sync(rt_engine* e);                                      /* waits for the engine's stream */
+/* FrameManager::GetTexturePixelsToPresent (FrameManager.cpp:60-71): waits, then copies the engine's own frame buffer. */
+int rt_engine_read_frame(rt_engine* e, uint8_t* rgba_out);
+/* Per-sample outputs (parity/debug).  rt_engine_keep_samples(e, 1) makes following renders record them; they can be read
+ * after an rt_engine_render with n_ranks == 1 on a frame that fits one batch:
+ * radiance[3] per sample, primary-hit object id (-1 = sky), primary HitInfo.distance, RNG draws.  Any pointer may be NULL.
+ * Sample order: pixel-major (row-major pixels), sample index sx*S+sy within the pixel. */
+int rt_engine_keep_samples(rt_engine* e, int enable);
+int rt_engine_read_samples(rt_engine* e, float* radiance3, int32_t* primary_id, float* primary_t, uint32_t* rng_draws);
+
+/* Closest-hit queries for arbitrary rays — World.cpp:105-119 (BVH + plane list merge).  Host arrays of n rays.
+ * hit_id: object id or -1.  rec9: distance, point[3], normal[3], uv[2]; for a miss distance holds what the reference's
+ * HitInfo.distance holds (FLT_MAX or a stale value, Object.cpp:17-19,534-550). */
+int rt_engine_trace(rt_engine* e, int n, const float* origins3, const float* dirs3, int32_t* hit_id, float* rec9);
+/* World::GetRayColor (World.cpp:104-171) for arbitrary rays, one RNG key per ray. */
+int rt_engine_ray_color(rt_engine* e, int n, const float* origins3, const float* dirs3, int bounces, const uint32_t* keys, float* rgb3);
+
+/* Counters of the last render (RT_FLAG_COUNT_STATS): paths, rays (closest-hit queries), rays per bounce level [0..32). */
+typedef struct rt_stats { uint64_t paths, rays; uint64_t rays_at_depth[33]; } rt_stats;
+int rt_engine_get_stats(rt_engine* e, rt_stats* out);
+/* Time of the dominant kernel over the last render, from HIP events recorded on the render stream around every
+ * launch of it: out[0] = total ms, out[1] = launches.  Only when enabled with rt_engine_time_kernels(e, 1). */
+int rt_engine_time_kernels(rt_engine* e, int enable);
+int rt_engine_kernel_times(rt_engine* e, double out2[2]);
+
+/* Device self-checks used by the tests: the portable sinf / atan2f and the RNG evaluated on the GPU. */
+int rt_engine_eval_math(rt_engine* e, int n, const float* x, const float* y, float* sin_x, float* atan2_yx);
+int rt_engine_eval_rng(rt_engine* e, int n, const uint32_t* key, const uint32_t* ctr, uint32_t* rand31, float* unit_distance);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,410 @@
+// Device-side building blocks of the renderer (gfx950): vector arithmetic in the reference's evaluation order, the keyed
+// counter RNG, portable sinf/atan2f, the primitive tests, the stackless two-level BVH traversal, hit finalisation and
+// shading.  Compiled with -ffp-contract=off: the reference's x86-64 build rounds every product and every sum separately,
+// and primary-hit ids and radiance are compared bit for bit.  File:line citations are relative to the reference's
+// Raytracer/src.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cstdint>
+
+#include "rt_flat.h"
+
+namespace rtd {
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+__device__ __forceinline__ V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ V3 divs(V3 a, float s) { return mk(a.x / s, a.y / s, a.z / s); }   // glm vec3 / scalar: true division
+// glm/detail/func_geometric.inl:48-55,68-79,82-90: dot = (x*x' + y*y') + z*z'; normalize = v * (1 / sqrt(dot))
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ V3 cross(V3 x, V3 y) { return mk(x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y); }
+__device__ __forceinline__ V3 normalize(V3 v) { float s = 1.0f / sqrtf(dot(v, v)); return v * s; }
+__device__ __forceinline__ float gmin(float x, float y) { return (y < x) ? y : x; }   // glm/detail/func_common.inl:20
+__device__ __forceinline__ float gmax(float x, float y) { return (x < y) ? y : x; }   // :29
+__device__ __forceinline__ float comp(V3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
+__device__ __forceinline__ void setc(V3& v, int i, float f) { if (i == 0) v.x = f; else if (i == 1) v.y = f; else v.z = f; }
+__device__ __forceinline__ V3 xyz(float4 f) { return mk(f.x, f.y, f.z); }
+
+// ---------------------------------------------------------------------------------------------------- RNG
+// Stand-in for std::rand (DataUtility.h:11-12): value i of stream `key` is fmix32(key ^ i*0x9E3779B9) >> 1 (31 bits, glibc's
+// RAND_MAX).  One stream per (frame seed, pixel, sample): the draws of a path never depend on another path.
+__device__ __forceinline__ uint32_t fmix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t rand31(uint32_t key, uint32_t ctr) { return fmix32(key ^ (ctr * 0x9E3779B9u)) >> 1; }
+__device__ __forceinline__ uint32_t sample_key(uint32_t seed, uint32_t pixel, uint32_t sample) {
+    uint32_t k = fmix32(seed ^ 0xA511E9B3u);
+    k = fmix32(k + pixel * 0x9E3779B1u + 0x68E31DA4u);
+    k = fmix32(k ^ (sample * 0x85EBCA77u + 0xC2B2AE3Du));
+    return k;
+}
+struct Rng { uint32_t key, ctr; };
+// RandomUnitDistance (DataUtility.h:12): (float)(rand() - RAND_MAX/2) / (RAND_MAX/2); the divisor converts to 2^30, so the
+// division is an exact scaling
+__device__ __forceinline__ float unit_distance(Rng& g) {
+    int r = (int)rand31(g.key, g.ctr++);
+    return (float)(r - 1073741823) * 9.31322574615478515625e-10f;
+}
+__device__ __forceinline__ V3 unit_sphere_point(Rng& g) {   // DataUtility.h:28-34
+    for (;;) {
+        V3 s;
+        s.x = unit_distance(g); s.y = unit_distance(g); s.z = unit_distance(g);
+        if (s.x * s.x + s.y * s.y + s.z * s.z < 1.0f) return s;
+    }
+}
+__device__ __forceinline__ void unit_circle_point(Rng& g, float& x, float& y) {   // DataUtility.h:35-41
+    for (;;) {
+        x = unit_distance(g); y = unit_distance(g);
+        if (x * x + y * y < 1.0f) return;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- portable sinf / atan2f
+// Evaluated in IEEE double with a fixed operation order (fdlibm's kernel polynomials) and rounded to float once: within
+// half an ulp of the true value almost everywhere, and the same bits on any IEEE machine — the CPU checker evaluates the
+// same formulas.  The reference calls libm's sinf/atan2f (DataUtility.cpp:91, World.cpp:174, Object.cpp:25).
+__device__ inline float pm_sinf(float x) {
+    if (!(fabsf(x) <= FLT_MAX)) return x - x;
+    const double TWO_OVER_PI = 6.36619772367581382433e-01;
+    const double P1 = 1.57079631090164184570e+00, P2 = 1.58932547122958567343e-08, P3 = 6.12323399573676603587e-17;
+    const double xd = (double)x;
+    const double k = rint(xd * TWO_OVER_PI);
+    const double r = ((xd - k * P1) - k * P2) - k * P3;
+    const int q = (int)(k - 4.0 * floor(k * 0.25));
+    const double z = r * r;
+    double res;
+    if (q & 1) {
+        const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                     C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+        const double p = z * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+        res = 1.0 - (0.5 * z - z * p);
+    } else {
+        const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                     S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+        const double p = S1 + z * (S2 + z * (S3 + z * (S4 + z * (S5 + z * S6))));
+        res = r + r * (z * p);
+    }
+    if (q & 2) res = -res;
+    return (float)res;
+}
+__device__ inline double pm_atan_pos(double x) {
+    double hi = 0.0, lo = 0.0;
+    int id = -1;
+    if (x < 0.4375) id = -1;
+    else if (x < 0.6875) { id = 0; x = (2.0 * x - 1.0) / (2.0 + x); hi = 4.63647609000806093515e-01; lo = 2.26987774529616870924e-17; }
+    else if (x < 1.1875) { id = 1; x = (x - 1.0) / (x + 1.0); hi = 7.85398163397448278999e-01; lo = 3.06161699786838301793e-17; }
+    else if (x < 2.4375) { id = 2; x = (x - 1.5) / (1.0 + 1.5 * x); hi = 9.82793723247329054082e-01; lo = 1.39033110312309984516e-17; }
+    else { id = 3; x = -1.0 / x; hi = 1.57079632679489655800e+00; lo = 6.12323399573676603587e-17; }
+    const double z = x * x, w = z * z;
+    const double s1 = z * (3.33333333333329318027e-01 + w * (1.42857142725034663711e-01 + w * (9.09088713343650656196e-02 +
+                      w * (6.66107313738753120669e-02 + w * (4.97687799461593236017e-02 + w * 1.62858201153657823623e-02)))));
+    const double s2 = w * (-1.99999999998764832476e-01 + w * (-1.11111104054623557880e-01 + w * (-7.69187620504482999495e-02 +
+                      w * (-5.83357013379057348645e-02 + w * -3.65315727442169155270e-02))));
+    if (id < 0) return x - x * (s1 + s2);
+    return hi - ((x * (s1 + s2) - lo) - x);
+}
+__device__ inline float pm_atan2f(float y, float x) {
+    if (!(fabsf(x) <= FLT_MAX) || !(fabsf(y) <= FLT_MAX)) return (x - x) + (y - y);
+    const double PI = 3.14159265358979311600e+00;
+    const double ax = fabs((double)x), ay = fabs((double)y);
+    double a;
+    if (ax == 0.0 && ay == 0.0) a = 0.0;
+    else a = pm_atan_pos(ay / ax);
+    if (__float_as_uint(x) >> 31) a = PI - a;
+    if (__float_as_uint(y) >> 31) a = -a;
+    return (float)a;
+}
+
+// ---------------------------------------------------------------------------------------------------- scene view
+struct Scene {
+    const float4* ent_lo; const float4* ent_hi;
+    const float4* tris; const float4* inst; const float4* objects; const float4* planes;
+    const rt::ImageRec* images; const uint8_t* texels;
+    uint32_t sky_off, sky_w, sky_h;
+    int top_end, stale_entry, n_planes;
+};
+struct Ray { V3 o, d; };
+
+// BoundingBox::DoesRayHit (DataUtility.cpp:35-82): true division per axis, branch on dir >= 0 (so -0.0 takes the >= branch),
+// NaN comparisons fall through as "not rejected".
+__device__ __forceinline__ bool box_hit(V3 mn, V3 mx, const Ray& r) {
+    const bool px = r.d.x >= 0, py = r.d.y >= 0, pz = r.d.z >= 0;
+    float tmin = ((px ? mn.x : mx.x) - r.o.x) / r.d.x;
+    float tmax = ((px ? mx.x : mn.x) - r.o.x) / r.d.x;
+    const float tymin = ((py ? mn.y : mx.y) - r.o.y) / r.d.y;
+    const float tymax = ((py ? mx.y : mn.y) - r.o.y) / r.d.y;
+    if ((tmin > tymax) || (tymin > tmax)) return false;
+    tmin = gmax(tmin, tymin);
+    tmax = gmin(tmax, tymax);
+    const float tzmin = ((pz ? mn.z : mx.z) - r.o.z) / r.d.z;
+    const float tzmax = ((pz ? mx.z : mn.z) - r.o.z) / r.d.z;
+    if ((tmin > tzmax) || (tzmin > tmax)) return false;
+    tmin = gmax(tmin, tzmin);
+    tmax = gmin(tmax, tzmax);
+    if (tmin < 0.0f && tmax < 0.0f) return false;
+    return true;
+}
+
+// Sphere::Intersect up to the accept/reject decision (Object.cpp:10-19).  The reference's sqrt() call binds to the double
+// overload, so distance = (float)((double)p1 - sqrt((double)p2sqr)).  `wrote` tells that HitInfo.distance was assigned
+// even though the test failed (near root behind the origin).
+__device__ __forceinline__ bool sphere_test(V3 c, float radius, const Ray& r, float& t, bool& wrote) {
+    const V3 L = r.o - c;
+    const float p1 = -dot(r.d, L);
+    const float p2sqr = p1 * p1 - dot(L, L) + radius * radius;
+    wrote = false;
+    if (p2sqr < 0) return false;
+    t = (float)((double)p1 - sqrt((double)p2sqr));
+    wrote = true;
+    return !(t < 0);
+}
+// AxisAlignedCube::Intersect (Object.cpp:36-119): entry distance and face normal (exit face when the origin is inside)
+__device__ __forceinline__ bool cube_test(V3 mn, V3 mx, const Ray& r, float& t, V3& normal) {
+    const bool px = r.d.x >= 0, py = r.d.y >= 0, pz = r.d.z >= 0;
+    float tmin = ((px ? mn.x : mx.x) - r.o.x) / r.d.x;
+    float tmax = ((px ? mx.x : mn.x) - r.o.x) / r.d.x;
+    V3 nmin = mk(px ? -1.0f : 1.0f, 0, 0), nmax = nmin;
+    const float tymin = ((py ? mn.y : mx.y) - r.o.y) / r.d.y;
+    const float tymax = ((py ? mx.y : mn.y) - r.o.y) / r.d.y;
+    V3 cand = mk(0, py ? -1.0f : 1.0f, 0);
+    if ((tmin > tymax) || (tymin > tmax)) return false;
+    if (tymin > tmin) { tmin = tymin; nmin = cand; }
+    if (tymax < tmax) { tmax = tymax; nmax = cand; }
+    const float tzmin = ((pz ? mn.z : mx.z) - r.o.z) / r.d.z;
+    const float tzmax = ((pz ? mx.z : mn.z) - r.o.z) / r.d.z;
+    cand = mk(0, 0, pz ? -1.0f : 1.0f);
+    if ((tmin > tzmax) || (tzmin > tmax)) return false;
+    if (tzmin > tmin) { tmin = tzmin; nmin = cand; }
+    if (tzmax < tmax) { tmax = tzmax; nmax = cand; }
+    if (tmin < 0.0f && tmax < 0.0f) return false;
+    if (tmin < 0) { nmin = nmax; tmin = tmax; }
+    t = tmin;
+    normal = nmin;
+    return true;
+}
+// float -> unsigned as the reference's x86-64 build converts it (glm::uvec2 cast, Object.cpp:545): truncate to 64 bits
+// signed, keep the low 32
+__device__ __forceinline__ uint32_t f2u_x86(float f) {
+    if (f >= 0.0f && f < 2147483648.0f) return (uint32_t)(int)f;
+    if (!(f > -9.2233720368547758e18f && f < 9.2233720368547758e18f)) return 0u;
+    return (uint32_t)(unsigned long long)(long long)f;
+}
+__device__ __forceinline__ int image_index(const rt::ImageRec im, float u, float v) {   // DataUtility.h:82 (uvec2 size: unsigned arithmetic)
+    const uint32_t row = (uint32_t)(int)(v * (float)im.h), col = (uint32_t)(int)(u * (float)im.w);
+    return 4 * (int)(row * im.w + col);
+}
+// Triangle::Intersect (Object.cpp:498-550).  alpha_img >= 0: the material's image texture decides solidity
+// (DataUtility.cpp:123-127).  `wrote`: HitInfo.distance was assigned although the triangle was rejected by the cut-out.
+__device__ __forceinline__ bool tri_test(const Scene& sc, int ti, int alpha_img, const Ray& r, float& t, float& uo, float& vo, bool& wrote) {
+    const float EPSILON = 0.0000001f;
+    const float4* T = sc.tris + (size_t)ti * rt::RT_TRI_F4;
+    const V3 v0 = xyz(T[0]), v1 = xyz(T[1]), v2 = xyz(T[2]);
+    wrote = false;
+    const V3 edge1 = v1 - v0, edge2 = v2 - v0;
+    const V3 h = cross(r.d, edge2);
+    const float a = dot(edge1, h);
+    if (a > -EPSILON && a < EPSILON) return false;
+    const float f = 1.0f / a;
+    const V3 s = r.o - v0;
+    const float u = f * dot(s, h);
+    if (u < 0.0f || u > 1.0f) return false;
+    const V3 q = cross(s, edge1);
+    const float v = f * dot(r.d, q);
+    if (v < 0.0f || u + v > 1.0f) return false;
+    const float tt = f * dot(edge2, q);
+    if (!(tt > EPSILON)) return false;
+    const V3 hp = r.o + r.d * tt;
+    const V3 p1 = v0, p2 = v1, p3 = v2;
+    const float denominator = p1.y * (p2.z - p3.z) - p2.y * (p1.z - p3.z) + p3.y * (p1.z - p2.z);
+    if (denominator == 0) return false;
+    t = tt;
+    wrote = true;
+    const float4 t3 = T[3], t4 = T[4];
+    const float percent0 = (hp.y * (p2.z - p3.z) - hp.z * (p2.y - p3.y) + p2.y * p3.z - p3.y * p2.z) / denominator;
+    const float percent1 = -(hp.y * (p1.z - p3.z) - hp.z * (p1.y - p3.y) + p1.y * p3.z - p3.y * p1.z) / denominator;
+    const float percent2 = (hp.y * (p1.z - p2.z) - hp.z * (p1.y - p2.y) + p1.y * p2.z - p2.y * p1.z) / denominator;
+    float uu = t3.x * percent0 + t3.z * percent1 + t4.x * percent2;
+    float vv = t3.y * percent0 + t3.w * percent1 + t4.y * percent2;
+    uu -= (float)f2u_x86(uu);
+    vv -= (float)f2u_x86(vv);
+    if (uu < 0) uu += 1;
+    if (vv < 0) vv += 1;
+    uo = uu; vo = vv;
+    if (alpha_img >= 0) {
+        const rt::ImageRec im = sc.images[alpha_img];
+        const uint8_t alpha = sc.texels[im.offset + (uint32_t)(image_index(im, uu, vv) + 3)];
+        if (!((float)alpha > 0.01f)) return false;
+    }
+    return true;
+}
+
+// ApplyMovement::Intersect + RotationIntersect on the way in (Object.cpp:601-603, 306-316)
+__device__ __forceinline__ Ray to_instance(const float4 i0, const float4 i1, const float4 i2, const Ray& r) {
+    Ray q = r;
+    if (i0.w != 0.0f) q.o = r.o - xyz(i0);
+    const int axis = __float_as_int(i1.w);
+    if (axis >= 0) {
+        const int a1 = axis == 0 ? 1 : 0, a2 = axis == 2 ? 1 : 2;
+        const float sinT = i2.x, cosT = i2.y;
+        const V3 pivot = xyz(i1);
+        const V3 oo = q.o - pivot;
+        V3 om = oo, dir = q.d;
+        setc(om, a1, cosT * comp(oo, a1) - sinT * comp(oo, a2));
+        setc(om, a2, sinT * comp(oo, a1) + cosT * comp(oo, a2));
+        setc(dir, a1, cosT * comp(q.d, a1) - sinT * comp(q.d, a2));
+        setc(dir, a2, sinT * comp(q.d, a1) + cosT * comp(q.d, a2));
+        q.o = om + pivot;
+        q.d = dir;
+    }
+    return q;
+}
+// and on the way out (Object.cpp:322-333, 606)
+__device__ __forceinline__ void from_instance(const float4 i0, const float4 i1, const float4 i2, V3& point, V3& normal) {
+    const int axis = __float_as_int(i1.w);
+    if (axis >= 0) {
+        const int a1 = axis == 0 ? 1 : 0, a2 = axis == 2 ? 1 : 2;
+        const float sinT = i2.x, cosT = i2.y;
+        const V3 pivot = xyz(i1);
+        const V3 oo = point - pivot;
+        V3 om = oo, n = normal;
+        setc(om, a1, cosT * comp(oo, a1) + sinT * comp(oo, a2));
+        setc(om, a2, -sinT * comp(oo, a1) + cosT * comp(oo, a2));
+        setc(n, a1, cosT * comp(normal, a1) + sinT * comp(normal, a2));
+        setc(n, a2, -sinT * comp(normal, a1) + cosT * comp(normal, a2));
+        point = om + pivot;
+        normal = n;
+    }
+    if (i0.w != 0.0f) point = point + xyz(i0);
+}
+
+// ---------------------------------------------------------------------------------------------------- closest hit
+// What World::GetRayColor learns from rootNode->Intersect plus the plane list (World.cpp:105-119).
+//   best >= 0: entry index of the winning leaf; best <= -2: plane -(best+2); best == -1: nothing hit.
+//   dist: HitInfo.distance as the reference leaves it — FLT_MAX, the winner's distance, or the stale value the leftmost
+//   leaf assigned before rejecting (Object.cpp:17-19, 534-550), which the plane is then compared against.
+struct Closest { float dist; int best; int inst; float u, v; bool hit; };
+
+__device__ inline void closest_hit(const Scene& sc, const Ray& ray, Closest& c) {
+    c.dist = FLT_MAX; c.best = -1; c.inst = -1; c.u = 0; c.v = 0; c.hit = false;
+    int i = 0, end = sc.top_end, resume = 0, inst = -1, stale = sc.stale_entry, alpha_img = -1;
+    Ray cur = ray;
+    for (;;) {
+        if (i >= end) {
+            if (inst < 0) break;
+            i = resume; end = sc.top_end; inst = -1; stale = sc.stale_entry; cur = ray;   // PolygonMesh / wrappers return
+            continue;
+        }
+        const float4 lo = sc.ent_lo[i], hi = sc.ent_hi[i];
+        const int kind = __float_as_int(hi.w);
+        if (kind == rt::ENT_INNER) {          // BVH_Node::Intersect (Object.cpp:241-252): left subtree, then right
+            i = box_hit(xyz(lo), xyz(hi), cur) ? i + 1 : __float_as_int(lo.w);
+            continue;
+        }
+        if (kind == rt::ENT_INSTANCE) {
+            const float4* I = sc.inst + (size_t)__float_as_int(lo.x) * rt::RT_INST_F4;
+            const float4 i0 = I[0], i1 = I[1], i2 = I[2], i3 = I[3];
+            cur = to_instance(i0, i1, i2, ray);
+            resume = i + 1;
+            stale = (i == sc.stale_entry) ? __float_as_int(i3.y) : -1;
+            inst = __float_as_int(lo.x);
+            const float4 ob = sc.objects[(size_t)__float_as_int(i3.x) * rt::RT_OBJ_F4];
+            alpha_img = __float_as_int(ob.y) == 2 ? __float_as_int(ob.z) : -1;
+            i = __float_as_int(i2.z);
+            end = __float_as_int(i2.w);
+            continue;
+        }
+        float t = 0, u = 0, v = 0;
+        bool ok, wrote = false;
+        if (kind == rt::ENT_SPHERE) ok = sphere_test(xyz(lo), lo.w, cur, t, wrote);
+        else if (kind == rt::ENT_CUBE) { V3 n; ok = cube_test(xyz(lo), xyz(hi), cur, t, n); }
+        else ok = tri_test(sc, __float_as_int(lo.x), alpha_img, cur, t, u, v, wrote);
+        if (ok) {
+            if (!c.hit || t < c.dist) { c.hit = true; c.dist = t; c.best = i; c.inst = inst; c.u = u; c.v = v; }
+        } else if (wrote && i == stale) c.dist = t;
+        i++;
+    }
+    for (int p = 0; p < sc.n_planes; p++) {   // YPlane::Intersect (Object.cpp:139-149), merged as World.cpp:110-118
+        const float t = -(ray.o.y - sc.planes[p].x) / ray.d.y;
+        if (t < 0.001f) continue;             // "t < 1e-3" against a double: the same floats pass
+        if (t < c.dist) { c.hit = true; c.dist = t; c.best = -(p + 2); c.inst = -1; }
+    }
+}
+
+struct Hit { V3 point, normal; float u, v; int object; };
+
+// The remaining HitInfo fields of the winning primitive (Object.cpp:21-25, 119-130, 145-147, 534-547 and the wrappers' way out)
+__device__ inline void finalize_hit(const Scene& sc, const Ray& ray, const Closest& c, Hit& h) {
+    h.u = 0; h.v = 0;
+    if (c.best <= -2) {
+        const float4 pl = sc.planes[-(c.best + 2)];
+        h.point = ray.o + ray.d * c.dist;
+        h.normal = mk(0.0f, 1.0f, 0.0f);
+        h.object = __float_as_int(pl.y);
+        return;
+    }
+    const float4 lo = sc.ent_lo[c.best], hi = sc.ent_hi[c.best];
+    const int kind = __float_as_int(hi.w);
+    if (kind == rt::ENT_SPHERE) {
+        h.point = ray.o + ray.d * c.dist;
+        h.normal = normalize(h.point - xyz(lo));
+        h.object = __float_as_int(hi.x);
+        h.u = pm_atan2f(h.normal.x, h.normal.z) / (2 * 3.14159265358979323846264338327950288f) + 0.5f;
+        h.v = h.normal.y * 0.5f + 0.5f;
+    } else if (kind == rt::ENT_CUBE) {
+        float t; V3 n;
+        const V3 mn = xyz(lo), mx = xyz(hi);
+        cube_test(mn, mx, ray, t, n);
+        h.normal = n;
+        h.object = __float_as_int(lo.w);
+        h.point = ray.o + ray.d * t;
+        h.point = h.point + n * 0.02f;
+        const V3 m01 = mk((h.point.x - mn.x) / (mx.x - mn.x), (h.point.y - mn.y) / (mx.y - mn.y), (h.point.z - mn.z) / (mx.z - mn.z));
+        if (n.x == 1 || n.x == -1) { h.u = m01.z; h.v = m01.y; }
+        else if (n.y == 1 || n.y == -1) { h.u = m01.x; h.v = m01.z; }
+        else { h.u = m01.x; h.v = m01.y; }
+    } else {   // triangle inside a mesh instance
+        const float4* I = sc.inst + (size_t)c.inst * rt::RT_INST_F4;
+        const float4 i0 = I[0], i1 = I[1], i2 = I[2], i3 = I[3];
+        const Ray q = to_instance(i0, i1, i2, ray);
+        const float4* T = sc.tris + (size_t)__float_as_int(lo.x) * rt::RT_TRI_F4;
+        const V3 n = mk(T[4].z, T[4].w, T[5].x);
+        const V3 hp = q.o + q.d * c.dist;
+        h.point = hp + n * 0.01f;
+        h.normal = n;
+        from_instance(i0, i1, i2, h.point, h.normal);
+        h.object = __float_as_int(i3.x);   // PolygonMesh::Intersect reports the mesh, not the triangle (Object.cpp:490-495)
+        h.u = c.u; h.v = c.v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- shading
+// World::GetSkyboxPixel (World.cpp:173-193): equirectangular nearest lookup without clamping
+__device__ inline V3 skybox_pixel(const Scene& sc, V3 d) {
+    const float u = pm_atan2f(d.x, d.z) / (2 * 3.14159265358979323846264338327950288f) + 0.5f;
+    const float v = d.y * 0.5f + 0.5f;
+    const int ix = (int)(u * (float)sc.sky_w), iy = (int)(v * (float)sc.sky_h);
+    const int index = 3 * (int)((uint32_t)iy * sc.sky_w + (uint32_t)ix);
+    const uint8_t* p = sc.texels + sc.sky_off + (uint32_t)index;
+    return divs(mk((float)p[0], (float)p[1], (float)p[2]), 255.0f);
+}
+// Texture::GetColorValue of the three texture classes (DataUtility.h:91, DataUtility.cpp:84-96, 113-121)
+__device__ inline V3 texture_color(const Scene& sc, const float4* ob, const Hit& h) {
+    const int kind = __float_as_int(ob[0].y);
+    if (kind == 0) return xyz(ob[1]);
+    if (kind == 1) {
+        const float scale = 5.0f;
+        const float sines = pm_sinf(scale * h.point.x) * pm_sinf(scale * h.point.y) * pm_sinf(scale * h.point.z);
+        return (sines < 0.0f) ? xyz(ob[1]) : xyz(ob[2]);
+    }
+    const rt::ImageRec im = sc.images[__float_as_int(ob[0].z)];
+    const uint8_t* p = sc.texels + im.offset + (uint32_t)image_index(im, h.u, h.v);
+    return divs(mk((float)p[0], (float)p[1], (float)p[2]), 255.0f);
+}
+
+}  // namespace rtd

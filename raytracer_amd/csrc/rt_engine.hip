@@ -1,0 +1,726 @@
+// MI355X engine: wavefront-batched path tracing of the reference's per-pixel path.
+//
+//   bounce kernel, first pass : generate (camera ray + lens sample, World.cpp:68-88) -> intersect -> shade -> compact
+//   bounce kernel, later pass : read a compacted ray queue                            -> intersect -> shade -> compact
+//   resolve kernel            : per pixel, sum the samples in the reference's order, tone-map, pack [A,B,G,R]
+//
+// A path is one pixel sample.  It owns a slot in the batch; its RNG stream is keyed by (frame seed, pixel, sample), so
+// the result of a slot does not depend on scheduling.  The recursion of World::GetRayColor (World.cpp:104-171) becomes
+// a loop over bounce kernels: each pass writes the surviving rays, compacted with a wave64 ballot + prefix count, into
+// the other queue.  The recursion multiplies colours on the way back (innermost first); to reproduce that rounding
+// order every bounce stores its (factor, texture colour) in a per-slot stack which the terminating pass unwinds.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rt_engine.h"
+#include "rt_device.h"
+#include "rt_host.h"
+
+using namespace rtd;
+
+namespace {
+
+struct Cam { V3 pos, fwd, u, v; };
+struct Cfg { int W, H, S, B; float fov, sky, dof, focus; };
+// which pixels a batch covers: pixels are enumerated tile by tile over the tiles this rank owns
+struct Batch {
+    int first_pixel, n_pixels;       // in the rank's pixel enumeration
+    int rank, n_ranks, tiles_x, n_tiles, tile_w, tile_h;
+    int wx0, wy0, ww, wh;            // render window inside the frame (the whole frame unless a test narrows it)
+    uint32_t seed;
+};
+struct Queues {
+    float4* a[2]; float4* b[2];      // ray records: a = (o.xyz, d.x), b = (d.y, d.z, slot, ctr | depth << 24)
+    uint32_t* counts;                // counts[k] = rays entering bounce pass k
+    float4* stack;                   // [depth][slot] = (texture colour rgb, factor)
+    float4* radiance;                // [slot] = sample radiance
+    int capacity;                    // slots
+};
+struct Debug { int32_t* primary_id; float* primary_t; uint32_t* rng_draws; const uint32_t* keys; };
+
+__device__ __forceinline__ bool pixel_of(const Batch& bt, const Cfg& g, int lp, int& px, int& py) {
+    const int per_tile = bt.tile_w * bt.tile_h;
+    const int t = lp / per_tile, in = lp - t * per_tile;
+    const int tile = bt.rank + t * bt.n_ranks;
+    if (tile >= bt.n_tiles) return false;
+    const int ty = tile / bt.tiles_x, tx = tile - ty * bt.tiles_x;
+    py = ty * bt.tile_h + in / bt.tile_w;
+    px = tx * bt.tile_w + in % bt.tile_w;
+    if (px >= bt.ww || py >= bt.wh) return false;
+    px += bt.wx0; py += bt.wy0;
+    return true;
+}
+
+// World::CalculateColorForScreenPosition, one sample (World.cpp:70-88)
+__device__ __forceinline__ Ray camera_ray(const Cam& cam, const Cfg& g, int px, int py, int sx, int sy, Rng& rng) {
+    const float one_x = -(1.0f / g.W) * ((float)g.W / g.H) * g.fov, one_y = -(1.0f / g.H) * g.fov;
+    const float off_x = -((float)px / g.W - 0.5f) * ((float)g.W / g.H) * g.fov, off_y = -((float)py / g.H - 0.5f) * g.fov;
+    Ray r;
+    r.d = cam.fwd + (cam.u * (off_x + one_x * ((float)sx / g.S)) + cam.v * (off_y + one_y * ((float)sy / g.S)));
+    r.d = normalize(r.d);
+    float lx, ly;
+    unit_circle_point(rng, lx, ly);
+    lx = lx * g.dof; ly = ly * g.dof;
+    const V3 wo = cam.u * lx + cam.v * ly;
+    r.o = cam.pos + wo;
+    r.d = r.d - divs(wo, g.focus);
+    r.d = normalize(r.d);
+    return r;
+}
+
+// One bounce pass.  FIRST: the lane's ray comes from the camera; otherwise from queue `qin`.
+template <bool FIRST>
+__global__ __launch_bounds__(256) void bounce_kernel(Scene sc, Cam cam, Cfg g, Batch bt, Queues q, int pass, Debug dbg) {
+    const int qin = (pass + 1) & 1, qout = pass & 1;
+    const uint32_t n_in = FIRST ? (uint32_t)bt.n_pixels * (uint32_t)(g.S * g.S) : q.counts[pass];
+    const uint32_t n_round = (n_in + 63u) & ~63u;   // whole waves stay together for the ballots below
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x) {
+        bool live = i < n_in;
+        Ray ray;
+        Rng rng;
+        uint32_t slot = 0, depth = 0;
+        ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1); rng.key = 0; rng.ctr = 0;
+        if (live) {
+            if (FIRST) {
+                slot = i;
+                const int spp = g.S * g.S;
+                const int lp = (int)(i / (uint32_t)spp), s = (int)(i - (uint32_t)lp * (uint32_t)spp);
+                int px, py;
+                live = pixel_of(bt, g, bt.first_pixel + lp, px, py);
+                if (live) {
+                    rng.key = dbg.keys ? dbg.keys[slot] : sample_key(bt.seed, (uint32_t)(py * g.W + px), (uint32_t)s);
+                    ray = camera_ray(cam, g, px, py, s / g.S, s % g.S, rng);
+                }
+            } else {
+                const float4 a = q.a[qin][i], b = q.b[qin][i];
+                ray.o = mk(a.x, a.y, a.z); ray.d = mk(a.w, b.x, b.y);
+                slot = __float_as_uint(b.z);
+                const uint32_t cd = __float_as_uint(b.w);
+                rng.ctr = cd & 0xFFFFFFu; depth = cd >> 24;
+                if (dbg.keys) rng.key = dbg.keys[slot];
+                else {
+                    const int spp = g.S * g.S;
+                    const int lp = (int)(slot / (uint32_t)spp), s = (int)(slot - (uint32_t)lp * (uint32_t)spp);
+                    int px, py;
+                    pixel_of(bt, g, bt.first_pixel + lp, px, py);
+                    rng.key = sample_key(bt.seed, (uint32_t)(py * g.W + px), (uint32_t)s);
+                }
+            }
+        }
+        bool alive = false;        // continues into the next pass
+        Ray next = ray;
+        if (live) {
+            // ---- intersect (World.cpp:105-119)
+            Closest c;
+            closest_hit(sc, ray, c);
+            if (FIRST) {
+                if (dbg.primary_t) dbg.primary_t[slot] = c.dist;
+                if (dbg.primary_id) {
+                    int id = -1;
+                    if (c.hit) { Hit h0; finalize_hit(sc, ray, c, h0); id = h0.object; }
+                    dbg.primary_id[slot] = id;
+                }
+            }
+            // ---- shade (World.cpp:121-170)
+            V3 L = mk(0, 0, 0);
+            if (!c.hit) L = skybox_pixel(sc, ray.d) * g.sky;
+            else {
+                Hit h;
+                finalize_hit(sc, ray, c, h);
+                const float4* ob = sc.objects + (size_t)h.object * rt::RT_OBJ_F4;
+                const int mtype = __float_as_int(ob[0].x);
+                const int remaining = g.B - (int)depth;       // the recursion's bounceAmount
+                if (mtype == RT_MAT_LIGHT) L = xyz(ob[3]);
+                else if (mtype != RT_MAT_NONE && remaining != 0) {
+                    float factor = 1.0f;
+                    next.o = h.point;
+                    if (mtype == RT_MAT_DIFFUSE) {
+                        next.d = normalize(h.normal + unit_sphere_point(rng));
+                        factor = 0.5f;                        // lightDarknerFactor (World.cpp:129)
+                    } else if (mtype == RT_MAT_METAL) {
+                        next.d = normalize(ray.d - (h.normal * 2.0f) * dot(ray.d, h.normal));
+                    } else next.d = unit_sphere_point(rng);    // Isotropic (World.cpp:163)
+                    const V3 tex = texture_color(sc, ob, h);
+                    q.stack[(size_t)depth * q.capacity + slot] = make_float4(tex.x, tex.y, tex.z, factor);
+                    alive = true;
+                }
+            }
+            if (!alive) {
+                // unwind the recursion: colour = (factor * child) * texture, innermost first (World.cpp:138,151,166)
+                for (int k = (int)depth - 1; k >= 0; k--) {
+                    const float4 st = q.stack[(size_t)k * q.capacity + slot];
+                    L = (L * st.w) * mk(st.x, st.y, st.z);
+                }
+                q.radiance[slot] = make_float4(L.x, L.y, L.z, 0.0f);
+                if (dbg.rng_draws) dbg.rng_draws[slot] = rng.ctr;
+            }
+        }
+        // ---- compact: survivors of this wave take consecutive places in the outgoing queue
+        const unsigned long long mask = __ballot(alive);
+        if (mask) {
+            const int lane = (int)(threadIdx.x & 63u);
+            const int leader = __ffsll((long long)mask) - 1;
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&q.counts[pass + 1], (uint32_t)__popcll(mask));
+            base = (uint32_t)__shfl((int)base, leader);
+            if (alive) {
+                const uint32_t at = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+                q.a[qout][at] = make_float4(next.o.x, next.o.y, next.o.z, next.d.x);
+                q.b[qout][at] = make_float4(next.d.y, next.d.z, __uint_as_float(slot), __uint_as_float(rng.ctr | ((depth + 1u) << 24)));
+            }
+        }
+    }
+}
+
+// World.cpp:94-100 + FrameManager.cpp:89-94.  (char)(c * 255): truncation, then the low byte.
+__device__ __forceinline__ uint32_t to_u8(float c) { return (uint32_t)(int)(c * 255) & 0xFFu; }
+__global__ __launch_bounds__(256) void resolve_kernel(Cfg g, Batch bt, const float4* radiance, uint8_t* out, int packed) {
+    const int lp = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lp >= bt.n_pixels) return;
+    int px, py;
+    const int glp = bt.first_pixel + lp;
+    if (!pixel_of(bt, g, glp, px, py)) return;
+    const int spp = g.S * g.S;
+    V3 color = mk(0, 0, 0);
+    const float4* r = radiance + (size_t)lp * spp;
+    for (int s = 0; s < spp; s++) { const float4 v = r[s]; color = color + mk(v.x, v.y, v.z); }
+    color = divs(color, (float)spp);
+    const float steepness = 5.0f;
+    color = mk(1.0f - 1.0f / (1.0f + steepness * color.x), 1.0f - 1.0f / (1.0f + steepness * color.y), 1.0f - 1.0f / (1.0f + steepness * color.z));
+    const uint32_t word = 255u | (to_u8(color.z) << 8) | (to_u8(color.y) << 16) | (to_u8(color.x) << 24);
+    // packed: tile slot-major layout for the gather; otherwise the final frame
+    const size_t at = packed ? (size_t)glp : (size_t)py * g.W + px;
+    reinterpret_cast<uint32_t*>(out)[at] = word;
+}
+// scatter gathered per-rank tile buffers into the frame
+__global__ __launch_bounds__(256) void assemble_kernel(Cfg g, Batch bt, const uint32_t* gathered, long long per_rank_pixels, uint32_t* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per_rank_pixels * bt.n_ranks) return;
+    Batch b = bt;
+    b.rank = (int)(i / per_rank_pixels);
+    int px, py;
+    if (!pixel_of(b, g, (int)(i - (long long)b.rank * per_rank_pixels), px, py)) return;
+    out[(size_t)py * g.W + px] = gathered[i];
+}
+
+// closest-hit queries for arbitrary rays
+__global__ __launch_bounds__(256) void trace_kernel(Scene sc, int n, const float* o3, const float* d3, int32_t* hit_id, float* rec9) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Ray r;
+    r.o = mk(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]);
+    r.d = mk(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]);
+    Closest c;
+    closest_hit(sc, r, c);
+    float* q = rec9 + 9 * (size_t)i;
+    q[0] = c.dist;
+    if (!c.hit) { hit_id[i] = -1; for (int k = 1; k < 9; k++) q[k] = 0; return; }
+    Hit h;
+    finalize_hit(sc, r, c, h);
+    hit_id[i] = h.object;
+    q[1] = h.point.x; q[2] = h.point.y; q[3] = h.point.z; q[4] = h.normal.x; q[5] = h.normal.y; q[6] = h.normal.z; q[7] = h.u; q[8] = h.v;
+}
+__global__ void load_rays_kernel(int n, const float* o3, const float* d3, float4* a, float4* b, uint32_t* count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *count = (uint32_t)n;
+    if (i >= n) return;
+    a[i] = make_float4(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2], d3[3 * i]);
+    b[i] = make_float4(d3[3 * i + 1], d3[3 * i + 2], __uint_as_float((uint32_t)i), __uint_as_float(0u));
+}
+__global__ void math_kernel(int n, const float* x, const float* y, float* s, float* a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    s[i] = pm_sinf(x[i]);
+    a[i] = pm_atan2f(y[i], x[i]);
+}
+__global__ void rng_kernel(int n, const uint32_t* key, const uint32_t* ctr, uint32_t* r31, float* ud) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    r31[i] = rand31(key[i], ctr[i]);
+    Rng g; g.key = key[i]; g.ctr = ctr[i];
+    ud[i] = unit_distance(g);
+}
+
+int fail(int code, const std::string& msg) { rt::set_error(msg); return code; }
+#define HIP_TRY(expr)                                                                                          \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess) return fail(RT_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+template <typename T>
+int upload(T** dst, const void* src, size_t bytes) {
+    *dst = nullptr;
+    HIP_TRY(hipMalloc((void**)dst, bytes ? bytes : 16));
+    if (bytes) HIP_TRY(hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice));
+    return RT_OK;
+}
+
+}  // namespace
+
+struct rt_engine {
+    rt_config cfg;
+    hipStream_t stream = nullptr;
+    Scene sc{};
+    bool have_scene = false, have_camera = false;
+    Cam cam{};
+    std::vector<void*> scene_allocs;
+    Queues q{};
+    int n_counts = 0;
+    uint8_t* d_frame = nullptr;
+    Debug dbg{nullptr, nullptr, nullptr, nullptr};
+    bool debug_valid = false;
+    int grid_blocks = 0;
+    int win[4] = {0, 0, 0, 0};          // x0, y0, width, height of the render window
+    // statistics of the last render
+    std::vector<uint32_t> h_counts;     // per batch x (B + 2)
+    uint32_t* d_counts_all = nullptr;
+    int counts_capacity = 0, last_batches = 0;
+    uint64_t last_paths = 0;
+    bool time_kernels = false;
+    std::vector<hipEvent_t> ev;
+    size_t ev_used = 0;
+};
+
+namespace {
+
+Cfg make_cfg(const rt_config& c) { return Cfg{c.width, c.height, c.samples_per_axis, c.bounces, c.fov, c.skybox_brightness, c.dof_intensity, c.focus_distance}; }
+
+void free_scene(rt_engine* e) {
+    for (void* p : e->scene_allocs) (void)hipFree(p);
+    e->scene_allocs.clear();
+    e->have_scene = false;
+}
+
+int tiles_x(const rt_engine* e) { return (e->win[2] + e->cfg.tile_w - 1) / e->cfg.tile_w; }
+int tiles_y(const rt_engine* e) { return (e->win[3] + e->cfg.tile_h - 1) / e->cfg.tile_h; }
+int tiles_per_rank(const rt_engine* e, int n_ranks) { return (tiles_x(e) * tiles_y(e) + n_ranks - 1) / n_ranks; }
+
+Batch make_batch(const rt_engine* e, int rank, int n_ranks, uint32_t seed) {
+    const rt_config& c = e->cfg;
+    Batch b;
+    b.first_pixel = 0; b.n_pixels = 0; b.rank = rank; b.n_ranks = n_ranks;
+    b.tiles_x = tiles_x(e); b.n_tiles = tiles_x(e) * tiles_y(e); b.tile_w = c.tile_w; b.tile_h = c.tile_h; b.seed = seed;
+    b.wx0 = e->win[0]; b.wy0 = e->win[1]; b.ww = e->win[2]; b.wh = e->win[3];
+    return b;
+}
+
+hipEvent_t next_event(rt_engine* e) {
+    if (e->ev_used == e->ev.size()) {
+        hipEvent_t ev;
+        (void)hipEventCreate(&ev);
+        e->ev.push_back(ev);
+    }
+    return e->ev[e->ev_used++];
+}
+
+// the bounce passes of one batch: pass 0 generates, passes 1..B read the queue the previous pass filled
+int run_passes(rt_engine* e, const Batch& bt, hipStream_t st, uint32_t* counts, bool first_from_queue, int bounces) {
+    Queues q = e->q;
+    q.counts = counts;
+    Cfg g = make_cfg(e->cfg);
+    g.B = bounces;
+    for (int pass = 0; pass <= bounces; pass++) {
+        if (e->time_kernels) (void)hipEventRecord(next_event(e), st);
+        if (pass == 0 && !first_from_queue) {
+            const uint32_t n = (uint32_t)bt.n_pixels * (uint32_t)(g.S * g.S);
+            const int blocks = (int)std::min<uint32_t>((n + 255u) / 256u, (uint32_t)e->grid_blocks);
+            hipLaunchKernelGGL(bounce_kernel<true>, dim3(blocks), dim3(256), 0, st, e->sc, e->cam, g, bt, q, pass, e->dbg);
+        } else {
+            hipLaunchKernelGGL(bounce_kernel<false>, dim3(e->grid_blocks), dim3(256), 0, st, e->sc, e->cam, g, bt, q, pass, e->dbg);
+        }
+        if (e->time_kernels) (void)hipEventRecord(next_event(e), st);
+    }
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_engine_create(const rt_config* cfg, rt_engine** out) {
+    if (!cfg || !out) return fail(RT_E_INVALID, "null argument");
+    if (cfg->width <= 0 || cfg->height <= 0 || cfg->samples_per_axis <= 0 || cfg->bounces < 0 || cfg->bounces > 32)
+        return fail(RT_E_INVALID, "width, height and samples_per_axis must be positive, bounces within 0..32");
+    if (!(cfg->focus_distance != 0.0f)) return fail(RT_E_INVALID, "focus_distance must not be zero");
+    int n_dev = 0;
+    HIP_TRY(hipGetDeviceCount(&n_dev));
+    if (cfg->device < 0 || cfg->device >= n_dev) return fail(RT_E_DEVICE, "no such HIP device");
+    HIP_TRY(hipSetDevice(cfg->device));
+    rt_engine* e = new rt_engine();
+    e->cfg = *cfg;
+    if (e->cfg.tile_w <= 0) e->cfg.tile_w = 64;
+    if (e->cfg.tile_h <= 0) e->cfg.tile_h = 64;
+    const int spp = cfg->samples_per_axis * cfg->samples_per_axis;
+    long long want = e->cfg.max_batch_paths > 0 ? e->cfg.max_batch_paths : (1ll << 23);
+    // a batch holds whole pixels and at least one tile row of them
+    const long long min_paths = (long long)spp * 64;
+    if (want < min_paths) want = min_paths;
+    e->win[0] = 0; e->win[1] = 0; e->win[2] = cfg->width; e->win[3] = cfg->height;
+    const long long frame_paths = (long long)tiles_x(e) * tiles_y(e) * e->cfg.tile_w * e->cfg.tile_h * spp;
+    if (want > frame_paths) want = frame_paths;
+    const long long batch_pixels = want / spp;
+    e->q.capacity = (int)(batch_pixels * spp);
+    e->cfg.max_batch_paths = e->q.capacity;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
+    e->grid_blocks = prop.multiProcessorCount * 8;
+    HIP_TRY(hipStreamCreate(&e->stream));
+    const size_t cap = (size_t)e->q.capacity;
+    for (int k = 0; k < 2; k++) {
+        HIP_TRY(hipMalloc((void**)&e->q.a[k], cap * sizeof(float4)));
+        HIP_TRY(hipMalloc((void**)&e->q.b[k], cap * sizeof(float4)));
+    }
+    HIP_TRY(hipMalloc((void**)&e->q.stack, cap * sizeof(float4) * (size_t)std::max(1, cfg->bounces)));
+    HIP_TRY(hipMalloc((void**)&e->q.radiance, cap * sizeof(float4)));
+    HIP_TRY(hipMalloc((void**)&e->d_frame, (size_t)cfg->width * cfg->height * 4));
+    HIP_TRY(hipMemset(e->d_frame, 0, (size_t)cfg->width * cfg->height * 4));
+    e->n_counts = cfg->bounces + 2;
+    *out = e;
+    return RT_OK;
+}
+
+void rt_engine_destroy(rt_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->cfg.device);
+    (void)hipStreamSynchronize(e->stream);
+    free_scene(e);
+    for (int k = 0; k < 2; k++) { (void)hipFree(e->q.a[k]); (void)hipFree(e->q.b[k]); }
+    (void)hipFree(e->q.stack); (void)hipFree(e->q.radiance); (void)hipFree(e->d_frame); (void)hipFree(e->d_counts_all);
+    (void)hipFree(e->dbg.primary_id); (void)hipFree(e->dbg.primary_t); (void)hipFree(e->dbg.rng_draws);
+    for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
+    (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int rt_engine_get_config(const rt_engine* e, rt_config* out) {
+    if (!e || !out) return fail(RT_E_INVALID, "null argument");
+    *out = e->cfg;
+    return RT_OK;
+}
+
+int rt_engine_set_scene(rt_engine* e, const rt_scene* s) {
+    if (!e) return fail(RT_E_INVALID, "null engine");
+    const rt_scene_flat* f = rt_scene_get_flat(s);
+    if (!f) return fail(RT_E_INVALID, "scene is not built");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    free_scene(e);
+    Scene sc{};
+    float4 *lo, *hi, *tris, *inst, *objects, *planes;
+    rt::ImageRec* images;
+    uint8_t* texels;
+    if (int rc = upload(&lo, f->ent_lo.data(), f->ent_lo.size() * 16)) return rc;
+    e->scene_allocs.push_back(lo);
+    if (int rc = upload(&hi, f->ent_hi.data(), f->ent_hi.size() * 16)) return rc;
+    e->scene_allocs.push_back(hi);
+    if (int rc = upload(&tris, f->tris.data(), f->tris.size() * 16)) return rc;
+    e->scene_allocs.push_back(tris);
+    if (int rc = upload(&inst, f->inst.data(), f->inst.size() * 16)) return rc;
+    e->scene_allocs.push_back(inst);
+    if (int rc = upload(&objects, f->objects.data(), f->objects.size() * 16)) return rc;
+    e->scene_allocs.push_back(objects);
+    if (int rc = upload(&planes, f->planes.data(), f->planes.size() * 16)) return rc;
+    e->scene_allocs.push_back(planes);
+    if (int rc = upload(&images, f->images.data(), f->images.size() * sizeof(rt::ImageRec))) return rc;
+    e->scene_allocs.push_back(images);
+    if (int rc = upload(&texels, f->texels.data(), f->texels.size())) return rc;
+    e->scene_allocs.push_back(texels);
+    sc.ent_lo = lo; sc.ent_hi = hi; sc.tris = tris; sc.inst = inst; sc.objects = objects; sc.planes = planes;
+    sc.images = images; sc.texels = texels;
+    sc.sky_off = f->sky.offset; sc.sky_w = f->sky.w; sc.sky_h = f->sky.h;
+    sc.top_end = f->top_end; sc.stale_entry = f->stale_entry; sc.n_planes = (int)f->planes.size();
+    e->sc = sc;
+    e->have_scene = true;
+    return RT_OK;
+}
+
+int rt_engine_set_camera(rt_engine* e, const float c[12]) {
+    if (!e || !c) return fail(RT_E_INVALID, "null argument");
+    e->cam.pos = V3{c[0], c[1], c[2]}; e->cam.fwd = V3{c[3], c[4], c[5]}; e->cam.u = V3{c[6], c[7], c[8]}; e->cam.v = V3{c[9], c[10], c[11]};
+    e->have_camera = true;
+    return RT_OK;
+}
+
+int rt_engine_set_window(rt_engine* e, int x0, int y0, int x1, int y1) {
+    if (!e) return fail(RT_E_INVALID, "null engine");
+    if (x0 < 0 || y0 < 0 || x1 > e->cfg.width || y1 > e->cfg.height || x0 >= x1 || y0 >= y1) return fail(RT_E_INVALID, "window must be a non-empty rectangle inside the frame");
+    e->win[0] = x0; e->win[1] = y0; e->win[2] = x1 - x0; e->win[3] = y1 - y0;
+    e->debug_valid = false;
+    return RT_OK;
+}
+
+int64_t rt_engine_tile_bytes(const rt_engine* e, int n_ranks) {
+    if (!e || n_ranks <= 0) return -1;
+    return (int64_t)tiles_per_rank(e, n_ranks) * e->cfg.tile_w * e->cfg.tile_h * 4;
+}
+
+int rt_engine_render(rt_engine* e, uint32_t seed, int rank, int n_ranks, uint8_t* d_rgba, void* stream) {
+    if (!e) return fail(RT_E_INVALID, "null engine");
+    if (!e->have_scene || !e->have_camera) return fail(RT_E_INVALID, "set a scene and a camera before rendering");
+    if (n_ranks <= 0 || rank < 0 || rank >= n_ranks) return fail(RT_E_INVALID, "rank must be within [0, n_ranks)");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    uint8_t* out = d_rgba ? d_rgba : e->d_frame;
+    const rt_config& c = e->cfg;
+    const Cfg g = make_cfg(c);
+    const int spp = g.S * g.S;
+    const int per_tile = c.tile_w * c.tile_h;
+    const long long my_pixels = (long long)tiles_per_rank(e, n_ranks) * per_tile;
+    const int batch_pixels = e->q.capacity / spp;
+    const int n_batches = (int)((my_pixels + batch_pixels - 1) / batch_pixels);
+    if (n_batches * e->n_counts > e->counts_capacity) {
+        (void)hipFree(e->d_counts_all);
+        e->counts_capacity = n_batches * e->n_counts;
+        HIP_TRY(hipMalloc((void**)&e->d_counts_all, sizeof(uint32_t) * (size_t)e->counts_capacity));
+    }
+    HIP_TRY(hipMemsetAsync(e->d_counts_all, 0, sizeof(uint32_t) * (size_t)n_batches * e->n_counts, st));
+    if (n_ranks > 1) HIP_TRY(hipMemsetAsync(out, 0, (size_t)my_pixels * 4, st));
+    e->ev_used = 0;
+    e->last_batches = n_batches;
+    {   // samples of the pixels this rank owns
+        uint64_t px = 0;
+        const int n_tiles = tiles_x(e) * tiles_y(e);
+        for (int t = rank; t < n_tiles; t += n_ranks) {
+            const int ty = t / tiles_x(e), tx = t % tiles_x(e);
+            px += (uint64_t)std::min(c.tile_w, e->win[2] - tx * c.tile_w) * (uint64_t)std::min(c.tile_h, e->win[3] - ty * c.tile_h);
+        }
+        e->last_paths = px * (uint64_t)spp;
+    }
+    e->debug_valid = (n_ranks == 1 && n_batches == 1);
+    for (int b = 0; b < n_batches; b++) {
+        Batch bt = make_batch(e, rank, n_ranks, seed);
+        bt.first_pixel = b * batch_pixels;
+        bt.n_pixels = (int)std::min<long long>(batch_pixels, my_pixels - (long long)b * batch_pixels);
+        uint32_t* counts = e->d_counts_all + (size_t)b * e->n_counts;
+        if (int rc = run_passes(e, bt, st, counts, false, c.bounces)) return rc;
+        hipLaunchKernelGGL(resolve_kernel, dim3((bt.n_pixels + 255) / 256), dim3(256), 0, st, g, bt, e->q.radiance, out, n_ranks > 1 ? 1 : 0);
+    }
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_engine_assemble(rt_engine* e, const uint8_t* d_gathered, int n_ranks, uint8_t* d_rgba, void* stream) {
+    if (!e || !d_gathered || n_ranks <= 0) return fail(RT_E_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    uint8_t* out = d_rgba ? d_rgba : e->d_frame;
+    const long long per_rank = rt_engine_tile_bytes(e, n_ranks) / 4;
+    const long long total = per_rank * n_ranks;
+    Batch bt = make_batch(e, 0, n_ranks, 0);
+    hipLaunchKernelGGL(assemble_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, make_cfg(e->cfg), bt,
+                       reinterpret_cast<const uint32_t*>(d_gathered), per_rank, reinterpret_cast<uint32_t*>(out));
+    HIP_TRY(hipGetLastError());
+    return RT_OK;
+}
+
+int rt_engine_sync(rt_engine* e) {
+    if (!e) return fail(RT_E_INVALID, "null engine");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return RT_OK;
+}
+
+int rt_engine_read_frame(rt_engine* e, uint8_t* rgba_out) {
+    if (!e || !rgba_out) return fail(RT_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(rgba_out, e->d_frame, (size_t)e->cfg.width * e->cfg.height * 4, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_engine_keep_samples(rt_engine* e, int enable) {
+    if (!e) return fail(RT_E_INVALID, "null engine");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (enable && !e->dbg.primary_id) {
+        const size_t cap = (size_t)e->q.capacity;
+        HIP_TRY(hipMalloc((void**)&e->dbg.primary_id, cap * 4));
+        HIP_TRY(hipMalloc((void**)&e->dbg.primary_t, cap * 4));
+        HIP_TRY(hipMalloc((void**)&e->dbg.rng_draws, cap * 4));
+    } else if (!enable && e->dbg.primary_id) {
+        (void)hipFree(e->dbg.primary_id); (void)hipFree(e->dbg.primary_t); (void)hipFree(e->dbg.rng_draws);
+        e->dbg = Debug{nullptr, nullptr, nullptr, nullptr};
+    }
+    e->debug_valid = false;
+    return RT_OK;
+}
+
+int rt_engine_read_samples(rt_engine* e, float* radiance3, int32_t* primary_id, float* primary_t, uint32_t* rng_draws) {
+    if (!e) return fail(RT_E_INVALID, "null engine");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (!e->dbg.primary_id) return fail(RT_E_INVALID, "per-sample outputs are off: call rt_engine_keep_samples(e, 1) before rendering");
+    if (!e->debug_valid) return fail(RT_E_INVALID, "per-sample outputs need a single-rank render that fits one batch");
+    const rt_config& c = e->cfg;
+    const int spp = c.samples_per_axis * c.samples_per_axis;
+    const size_t slots = (size_t)e->q.capacity;
+    // slots are enumerated tile by tile; hand them back in row-major pixel order
+    std::vector<float4> rad;
+    std::vector<int32_t> pid;
+    std::vector<float> pt;
+    std::vector<uint32_t> draws;
+    if (radiance3) { rad.resize(slots); HIP_TRY(hipMemcpy(rad.data(), e->q.radiance, slots * 16, hipMemcpyDeviceToHost)); }
+    if (primary_id) { pid.resize(slots); HIP_TRY(hipMemcpy(pid.data(), e->dbg.primary_id, slots * 4, hipMemcpyDeviceToHost)); }
+    if (primary_t) { pt.resize(slots); HIP_TRY(hipMemcpy(pt.data(), e->dbg.primary_t, slots * 4, hipMemcpyDeviceToHost)); }
+    if (rng_draws) { draws.resize(slots); HIP_TRY(hipMemcpy(draws.data(), e->dbg.rng_draws, slots * 4, hipMemcpyDeviceToHost)); }
+    const int tx_n = tiles_x(e), per_tile = c.tile_w * c.tile_h, ww = e->win[2], wh = e->win[3];
+    for (int py = 0; py < wh; py++)
+        for (int px = 0; px < ww; px++) {
+            const int tile = (py / c.tile_h) * tx_n + px / c.tile_w;
+            const size_t lp = (size_t)tile * per_tile + (size_t)(py % c.tile_h) * c.tile_w + (px % c.tile_w);
+            const size_t dst = ((size_t)py * ww + px) * spp;
+            for (int s = 0; s < spp; s++) {
+                const size_t src = lp * spp + s;
+                if (radiance3) { radiance3[3 * (dst + s)] = rad[src].x; radiance3[3 * (dst + s) + 1] = rad[src].y; radiance3[3 * (dst + s) + 2] = rad[src].z; }
+                if (primary_id) primary_id[dst + s] = pid[src];
+                if (primary_t) primary_t[dst + s] = pt[src];
+                if (rng_draws) rng_draws[dst + s] = draws[src];
+            }
+        }
+    return RT_OK;
+}
+
+int rt_engine_trace(rt_engine* e, int n, const float* o3, const float* d3, int32_t* hit_id, float* rec9) {
+    if (!e || !o3 || !d3 || !hit_id || !rec9 || n < 0) return fail(RT_E_INVALID, "bad arguments");
+    if (!e->have_scene) return fail(RT_E_INVALID, "no scene set");
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    float *d_o = nullptr, *d_d = nullptr, *d_rec = nullptr;
+    int32_t* d_hit = nullptr;
+    int rc = RT_OK;
+    if ((rc = upload(&d_o, o3, (size_t)n * 12)) == RT_OK && (rc = upload(&d_d, d3, (size_t)n * 12)) == RT_OK) {
+        if (hipMalloc((void**)&d_hit, (size_t)n * 4) != hipSuccess || hipMalloc((void**)&d_rec, (size_t)n * 36) != hipSuccess)
+            rc = fail(RT_E_NOMEM, "device allocation failed");
+        else {
+            hipLaunchKernelGGL(trace_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->sc, n, d_o, d_d, d_hit, d_rec);
+            hipError_t he = hipStreamSynchronize(e->stream);
+            if (he != hipSuccess) rc = fail(RT_E_DEVICE, hipGetErrorString(he));
+            else {
+                (void)hipMemcpy(hit_id, d_hit, (size_t)n * 4, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(rec9, d_rec, (size_t)n * 36, hipMemcpyDeviceToHost);
+            }
+        }
+    }
+    (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_hit); (void)hipFree(d_rec);
+    return rc;
+}
+
+int rt_engine_ray_color(rt_engine* e, int n, const float* o3, const float* d3, int bounces, const uint32_t* keys, float* rgb3) {
+    if (!e || !o3 || !d3 || !keys || !rgb3 || n < 0) return fail(RT_E_INVALID, "bad arguments");
+    if (!e->have_scene) return fail(RT_E_INVALID, "no scene set");
+    if (bounces < 0 || bounces > e->cfg.bounces) return fail(RT_E_INVALID, "bounces must be within the engine's configured bounce count");
+    if (n > e->q.capacity) return fail(RT_E_INVALID, "more rays than the batch capacity");
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    float *d_o = nullptr, *d_d = nullptr;
+    uint32_t *d_keys = nullptr, *d_counts = nullptr;
+    int rc = RT_OK;
+    if ((rc = upload(&d_o, o3, (size_t)n * 12)) == RT_OK && (rc = upload(&d_d, d3, (size_t)n * 12)) == RT_OK &&
+        (rc = upload(&d_keys, keys, (size_t)n * 4)) == RT_OK) {
+        if (hipMalloc((void**)&d_counts, sizeof(uint32_t) * 40) != hipSuccess) rc = fail(RT_E_NOMEM, "device allocation failed");
+        else {
+            (void)hipMemsetAsync(d_counts, 0, sizeof(uint32_t) * 40, e->stream);
+            // the rays enter pass 0 through queue (0+1)&1 = 1
+            hipLaunchKernelGGL(load_rays_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, d_o, d_d, e->q.a[1], e->q.b[1], d_counts);
+            const Debug saved = e->dbg;
+            const bool saved_timing = e->time_kernels;
+            e->dbg = Debug{nullptr, nullptr, nullptr, d_keys};
+            e->time_kernels = false;
+            Batch bt = make_batch(e, 0, 1, 0);
+            bt.n_pixels = 0;
+            rc = run_passes(e, bt, e->stream, d_counts, true, bounces);
+            e->dbg = saved;
+            e->time_kernels = saved_timing;
+            hipError_t he = hipStreamSynchronize(e->stream);
+            if (rc == RT_OK && he != hipSuccess) rc = fail(RT_E_DEVICE, hipGetErrorString(he));
+            if (rc == RT_OK) {
+                std::vector<float4> rad((size_t)n);
+                (void)hipMemcpy(rad.data(), e->q.radiance, (size_t)n * 16, hipMemcpyDeviceToHost);
+                for (int i = 0; i < n; i++) { rgb3[3 * i] = rad[i].x; rgb3[3 * i + 1] = rad[i].y; rgb3[3 * i + 2] = rad[i].z; }
+            }
+        }
+    }
+    (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_keys); (void)hipFree(d_counts);
+    e->debug_valid = false;
+    return rc;
+}
+
+int rt_engine_get_stats(rt_engine* e, rt_stats* out) {
+    if (!e || !out) return fail(RT_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    memset(out, 0, sizeof *out);
+    const int nb = e->last_batches, nc = e->n_counts;
+    if (nb <= 0) return RT_OK;
+    e->h_counts.resize((size_t)nb * nc);
+    HIP_TRY(hipMemcpy(e->h_counts.data(), e->d_counts_all, sizeof(uint32_t) * (size_t)nb * nc, hipMemcpyDeviceToHost));
+    for (int b = 0; b < nb; b++)
+        for (int k = 1; k < nc - 1 && k < 33; k++) out->rays_at_depth[k] += e->h_counts[(size_t)b * nc + k];
+    out->paths = e->last_paths;
+    out->rays_at_depth[0] = e->last_paths;
+    for (int k = 0; k < 33; k++) out->rays += out->rays_at_depth[k];
+    return RT_OK;
+}
+
+int rt_engine_time_kernels(rt_engine* e, int enable) {
+    if (!e) return fail(RT_E_INVALID, "null engine");
+    e->time_kernels = enable != 0;
+    e->ev_used = 0;
+    return RT_OK;
+}
+int rt_engine_kernel_times(rt_engine* e, double out2[2]) {
+    if (!e || !out2) return fail(RT_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    double total = 0;
+    for (size_t i = 0; i + 1 < e->ev_used; i += 2) {
+        HIP_TRY(hipEventSynchronize(e->ev[i + 1]));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, e->ev[i], e->ev[i + 1]));
+        total += ms;
+    }
+    out2[0] = total;
+    out2[1] = (double)(e->ev_used / 2);
+    return RT_OK;
+}
+
+int rt_engine_eval_math(rt_engine* e, int n, const float* x, const float* y, float* sin_x, float* atan2_yx) {
+    if (!e || !x || !y || !sin_x || !atan2_yx || n <= 0) return fail(RT_E_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    float *dx, *dy, *ds, *da;
+    if (int rc = upload(&dx, x, (size_t)n * 4)) return rc;
+    if (int rc = upload(&dy, y, (size_t)n * 4)) return rc;
+    HIP_TRY(hipMalloc((void**)&ds, (size_t)n * 4));
+    HIP_TRY(hipMalloc((void**)&da, (size_t)n * 4));
+    hipLaunchKernelGGL(math_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, dx, dy, ds, da);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(sin_x, ds, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(atan2_yx, da, (size_t)n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(ds); (void)hipFree(da);
+    return RT_OK;
+}
+int rt_engine_eval_rng(rt_engine* e, int n, const uint32_t* key, const uint32_t* ctr, uint32_t* r31, float* ud) {
+    if (!e || !key || !ctr || !r31 || !ud || n <= 0) return fail(RT_E_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    uint32_t *dk, *dc, *dr;
+    float* du;
+    if (int rc = upload(&dk, key, (size_t)n * 4)) return rc;
+    if (int rc = upload(&dc, ctr, (size_t)n * 4)) return rc;
+    HIP_TRY(hipMalloc((void**)&dr, (size_t)n * 4));
+    HIP_TRY(hipMalloc((void**)&du, (size_t)n * 4));
+    hipLaunchKernelGGL(rng_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, dk, dc, dr, du);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipMemcpy(r31, dr, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ud, du, (size_t)n * 4, hipMemcpyDeviceToHost));
+    (void)hipFree(dk); (void)hipFree(dc); (void)hipFree(dr); (void)hipFree(du);
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,35 @@
+// Device layout of a flattened scene.  Everything is arrays of 16-byte records so that each lane fetches a record with
+// one or two dwordx4 loads; integer fields are stored as the bit pattern of a float lane.
+//
+// Entries — the two BVH levels of the reference (BVH_Node over objects, Object.h:59-71; BVH_Node over a mesh's triangles,
+// Object.cpp:488) flattened in depth-first preorder, left child first, exactly the order BVH_Node::Intersect
+// (Object.cpp:241-252) visits them.  An inner node carries the index to continue at when its box is missed ("skip"), so
+// traversal needs no stack:  i = box_hit ? i + 1 : skip.   A node whose two children are the same object (span 1,
+// Object.cpp:198-200) lists that object once: testing it twice cannot change the result.
+//   kind INNER    lo = (min.x, min.y, min.z, skip)        hi = (max.x, max.y, max.z, kind)
+//   kind SPHERE   lo = (c.x, c.y, c.z, radius)            hi = (object id, 0, 0, kind)
+//   kind CUBE     lo = (min.x, min.y, min.z, object id)   hi = (max.x, max.y, max.z, kind)
+//   kind TRI      lo = (triangle index, 0, 0, 0)          hi = (0, 0, 0, kind)
+//   kind INSTANCE lo = (instance index, 0, 0, 0)          hi = (0, 0, 0, kind)
+// The top-level list occupies [0, top_end); each mesh instance owns a range [begin, end) after it.
+//
+// Triangle (RT_TRI_F4 = 6 records):  (v0.xyz, -) (v1.xyz, -) (v2.xyz, -) (uv0.xy, uv1.xy) (uv2.xy, n.x, n.y) (n.z, -, -, -)
+// Instance (RT_INST_F4 = 4):         (offset.xyz, has_move) (pivot.xyz, rot axis or -1) (sin, cos, begin, end)
+//                                    (object id, stale entry, 0, 0)
+// Object   (RT_OBJ_F4 = 4):          (material type, texture kind, image index, 0) (colour1.rgb, 0) (colour2.rgb, 0) (emit.rgb, 0)
+// Plane    (1):                      (y, object id, 0, 0)
+#pragma once
+#include <cstdint>
+
+namespace rt {
+
+struct F4 { float x, y, z, w; };
+struct ImageRec { uint32_t offset, w, h, channels; };   // byte offset into the texel pool
+
+enum : int { ENT_INNER = 0, ENT_SPHERE = 1, ENT_CUBE = 2, ENT_TRI = 3, ENT_INSTANCE = 4 };
+constexpr int RT_TRI_F4 = 6, RT_INST_F4 = 4, RT_OBJ_F4 = 4;
+
+inline float bits_f(int32_t i) { union { int32_t i; float f; } u; u.i = i; return u.f; }
+inline int32_t bits_i(float f) { union { int32_t i; float f; } u; u.f = f; return u.i; }
+
+}  // namespace rt

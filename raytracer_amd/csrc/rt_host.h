@@ -1,0 +1,61 @@
+// Host-side types shared by the scene builder, the asset decoders and the engine.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "rt_flat.h"
+
+namespace rt {
+
+struct Vec2 { float x, y; };
+struct Vec3 {
+    float x, y, z;
+    float operator[](int i) const { return i == 0 ? x : (i == 1 ? y : z); }
+    float& at(int i) { return i == 0 ? x : (i == 1 ? y : z); }
+};
+struct Box3 { Vec3 mn, mx; };
+
+// GLM 0.9.9.7 evaluation order (glm/detail/func_geometric.inl:48-90, func_common.inl:20,29): the scene constants
+// computed here must carry the same bits as the reference's.
+inline Vec3 operator+(Vec3 a, Vec3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline Vec3 operator-(Vec3 a, Vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline Vec3 operator*(Vec3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline float dot(Vec3 a, Vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline Vec3 cross(Vec3 x, Vec3 y) { return {x.y * y.z - y.y * x.z, x.z * y.x - y.z * x.x, x.x * y.y - y.x * x.y}; }
+inline Vec3 normalize(Vec3 v) { float s = 1.0f / std::sqrt(dot(v, v)); return v * s; }
+inline float gmin(float x, float y) { return (y < x) ? y : x; }
+inline float gmax(float x, float y) { return (x < y) ? y : x; }
+
+// keyed counter generator that stands in for std::rand (DataUtility.h:11-12) on the host (BVH axis choice) and on
+// the device (lens and bounce sampling): value i of stream `key` is fmix32(key ^ i*0x9E3779B9) >> 1, 31 bits
+// like glibc's RAND_MAX.
+inline uint32_t fmix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+inline uint32_t rand31(uint32_t key, uint32_t ctr) { return fmix32(key ^ (ctr * 0x9E3779B9u)) >> 1; }
+
+void set_error(const std::string& msg);
+
+bool load_obj(const std::string& path, std::vector<float>& verts8, std::string& err);
+bool load_png(const std::string& path, int req_channels, bool flip, std::vector<uint8_t>& out, int& w, int& h,
+              int& file_channels, std::string& err);
+
+}  // namespace rt
+
+// The flattened scene as the engine uploads it (layout: rt_flat.h).
+struct rt_scene_flat {
+    std::vector<rt::F4> ent_lo, ent_hi;      // threaded preorder entries
+    std::vector<rt::F4> tris;                // RT_TRI_F4 float4 per triangle
+    std::vector<rt::F4> inst;                // RT_INST_F4 float4 per mesh instance
+    std::vector<rt::F4> objects;             // RT_OBJ_F4 float4 per object id
+    std::vector<rt::F4> planes;              // (y, object id bits, 0, 0)
+    std::vector<rt::ImageRec> images;
+    std::vector<uint8_t> texels;             // all images then the skybox, each padded by one row
+    rt::ImageRec sky{0, 0, 0, 0};
+    int32_t top_end = 0, stale_entry = -1;
+};
+
+const rt_scene_flat* rt_scene_get_flat(const struct rt_scene* s);

@@ -1,0 +1,672 @@
+// Host scene builder: the object graph of the reference (Object.h) as a flat pool, the reference's BVH construction
+// (BVH_Node::BVH_Node, Object.cpp:181-225) driven by the keyed counter RNG, and the flattening into the stackless
+// device layout described in rt_flat.h.  Also the host side of Camera (DataUtility.cpp:10-15) and the default scene
+// (World.cpp:15-32).
+#include "../../include/rt_engine.h"
+#include "rt_host.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cstring>
+#include <memory>
+
+using namespace rt;
+
+namespace {
+
+thread_local std::string g_error;
+
+enum Kind { SPHERE, CUBE, PLANE, TRI, NODE, MESH, ROT, MOVE };
+
+struct Obj {
+    Kind kind;
+    int material = -1, id = -1;
+    Vec3 c{0, 0, 0};
+    float r = 0;                      // sphere
+    Box3 box{{0, 0, 0}, {0, 0, 0}};   // cube extents; node / triangle / rotation box
+    float y = 0;                      // plane
+    Vec3 p[3]; Vec2 tc[3]; Vec3 n[3]; // triangle
+    int left = -1, right = -1;        // node
+    int root = -1;                    // mesh: its triangle BVH
+    int target = -1, axis = -1;       // wrappers
+    float sin_t = 0, cos_t = 0, degrees = 0;
+    Vec3 pivot{0, 0, 0}, offset{0, 0, 0};
+    std::vector<float> verts;         // mesh: parsed vertices until build
+    float size = 0;
+};
+struct Tex { int kind; Vec3 c1, c2; int image; };
+struct Mat { int type, tex; Vec3 emit; };
+struct Image { std::vector<uint8_t> px; int w, h, channels; };
+
+}  // namespace
+
+struct rt_scene {
+    std::vector<Obj> objs;
+    std::vector<Tex> texs;
+    std::vector<Mat> mats;
+    std::vector<Image> images;
+    Image sky{{}, 0, 0, 3};
+    std::vector<int> top, planes;
+    int root = -1, next_id = 0;
+    bool built = false;
+    uint32_t rng_key = 0, rng_ctr = 0;
+    rt_scene_flat flat;
+
+    float random01() { return (float)(int)rand31(rng_key, rng_ctr++) / 2147483648.0f; }   // DataUtility.h:11
+};
+
+namespace rt { void set_error(const std::string& m) { g_error = m; } }
+extern "C" const char* rt_last_error(void) { return g_error.c_str(); }
+const rt_scene_flat* rt_scene_get_flat(const rt_scene* s) { return s && s->built ? &s->flat : nullptr; }
+
+namespace {
+
+int fail(int code, const std::string& msg) { set_error(msg); return code; }
+
+Box3 box_of(const rt_scene& s, int idx) {
+    const Obj& o = s.objs[idx];
+    switch (o.kind) {
+    case SPHERE: {   // Object.cpp:29-35; a negative radius gives an inverted box and is kept that way
+        Vec3 rr{o.r, o.r, o.r};
+        return {o.c - rr, o.c + rr};
+    }
+    case MESH: return box_of(s, o.root);   // Object.h:97
+    case MOVE: {                           // Object.cpp:610-615
+        Box3 b = box_of(s, o.target);
+        return {b.mn + o.offset, b.mx + o.offset};
+    }
+    default: return o.box;
+    }
+}
+
+// BVH_Node::BVH_Node (Object.cpp:181-225).  The reference copies the object vector in every node and sorts a
+// sub-range of the copy; children only touch disjoint sub-ranges, so sorting one shared vector in place is the same.
+int build_node(rt_scene& s, std::vector<int>& list, int start, int end) {
+    const int axis_draw = (int)(s.random01() * 3);
+    const int axis = axis_draw == 0 ? 0 : (axis_draw == 1 ? 1 : 2);
+    auto less = [&s, axis](int a, int b) { return box_of(s, a).mn[axis] < box_of(s, b).mn[axis]; };
+    const int span = end - start;
+    int left, right;
+    if (span == 1) left = right = list[start];
+    else if (span == 2) {
+        if (less(list[start], list[start + 1])) { left = list[start]; right = list[start + 1]; }
+        else { left = list[start + 1]; right = list[start]; }
+    } else {
+        std::sort(list.begin() + start, list.begin() + end, less);
+        const int mid = start + span / 2;
+        left = build_node(s, list, start, mid);
+        right = build_node(s, list, mid, end);
+    }
+    const Box3 bl = box_of(s, left), br = box_of(s, right);
+    Obj node;
+    node.kind = NODE;
+    node.left = left;
+    node.right = right;
+    // GetSurroundingBox (Object.cpp:156-166): fmin / fmax per component
+    node.box.mn = {std::fmin(bl.mn.x, br.mn.x), std::fmin(bl.mn.y, br.mn.y), std::fmin(bl.mn.z, br.mn.z)};
+    node.box.mx = {std::fmax(bl.mx.x, br.mx.x), std::fmax(bl.mx.y, br.mx.y), std::fmax(bl.mx.z, br.mx.z)};
+    s.objs.push_back(node);
+    return (int)s.objs.size() - 1;
+}
+
+// PolygonMesh::PolygonMesh after parsing (Object.cpp:462-488): recentre, scale to `size`, one Triangle per 3 vertices
+// (box as Object.h:84), triangle BVH.
+void finish_mesh(rt_scene& s, int mesh_idx) {
+    const std::vector<float> vv = s.objs[mesh_idx].verts;
+    const int n_tri = (int)vv.size() / 24, nv = n_tri * 3;
+    const float size = s.objs[mesh_idx].size;
+    const int material = s.objs[mesh_idx].material, id = s.objs[mesh_idx].id;
+    Vec3 pmin{vv[0], vv[1], vv[2]}, pmax = pmin;
+    for (int i = 0; i < nv; i++) {
+        const Vec3 pt{vv[8 * i], vv[8 * i + 1], vv[8 * i + 2]};
+        pmin = {gmin(pmin.x, pt.x), gmin(pmin.y, pt.y), gmin(pmin.z, pt.z)};
+        pmax = {gmax(pmax.x, pt.x), gmax(pmax.y, pt.y), gmax(pmax.z, pt.z)};
+    }
+    const Vec3 center = pmin * 0.5f + pmax * 0.5f;
+    const Vec3 ext = pmax - pmin;
+    const float factor = size / gmax(gmax(ext.x, ext.y), ext.z);
+    std::vector<int> tris(n_tri);
+    for (int t = 0; t < n_tri; t++) {
+        Obj tri;
+        tri.kind = TRI;
+        tri.material = material;
+        tri.id = id;
+        for (int k = 0; k < 3; k++) {
+            const float* r = &vv[8 * (3 * t + k)];
+            tri.p[k] = (Vec3{r[0], r[1], r[2]} - center) * factor;
+            tri.tc[k] = {r[3], r[4]};
+            tri.n[k] = {r[5], r[6], r[7]};
+        }
+        for (int c = 0; c < 3; c++) {
+            tri.box.mn.at(c) = gmin(tri.p[0][c], gmin(tri.p[1][c], tri.p[2][c]));
+            tri.box.mx.at(c) = gmax(tri.p[0][c], gmax(tri.p[1][c], tri.p[2][c]));
+        }
+        s.objs.push_back(tri);
+        tris[t] = (int)s.objs.size() - 1;
+    }
+    const int root = build_node(s, tris, 0, n_tri);
+    s.objs[mesh_idx].root = root;
+}
+
+// InitializeRotationTransform (Object.cpp:254-292) with the axis pairs of Object.cpp:293-301
+void finish_rotation(rt_scene& s, int idx) {
+    Obj& o = s.objs[idx];
+    const float angle = o.degrees * 0.01745329251994329576923690768489f;   // glm::radians
+    o.sin_t = std::sin(angle);
+    o.cos_t = std::cos(angle);
+    Box3 box = box_of(s, o.target);
+    o.pivot = box.mn * (1.0f - 0.5f) + box.mx * 0.5f;   // glm::lerp(min, max, 0.5f) = mix
+    box.mn = box.mn - o.pivot;
+    box.mx = box.mx - o.pivot;
+    const int a1 = o.axis == 0 ? 1 : 0, a2 = o.axis == 2 ? 1 : 2, ra = o.axis;
+    Vec3 mn{FLT_MAX, FLT_MAX, FLT_MAX}, mx{FLT_MIN, FLT_MIN, FLT_MIN};   // numeric_limits<float>::min(), Object.cpp:265
+    for (int i = 0; i < 2; i++)
+        for (int j = 0; j < 2; j++)
+            for (int k = 0; k < 2; k++) {
+                const float axis1 = i * box.mx[a1] + (1 - i) * box.mn[a1];
+                const float axis2 = j * box.mx[a2] + (1 - j) * box.mn[a2];
+                const float rest = k * box.mx[ra] + (1 - k) * box.mn[ra];
+                Vec3 t{0, 0, 0};
+                t.at(a1) = o.cos_t * axis1 + o.sin_t * axis2;
+                t.at(a2) = -o.sin_t * axis1 + o.cos_t * axis2;
+                t.at(ra) = rest;
+                for (int c = 0; c < 3; c++) {
+                    mn.at(c) = std::fmin(mn[c], t[c]);
+                    mx.at(c) = std::fmax(mx[c], t[c]);
+                }
+            }
+    o.box = {mn + o.pivot, mx + o.pivot};
+}
+
+// ------------------------------------------------------------------------------------------------- flattening
+struct Flattener {
+    const rt_scene& s;
+    rt_scene_flat& f;
+    int first_leaf = -1;   // first leaf entry of the list being emitted
+
+    int emit_leaf(int idx, bool top_level) {
+        const Obj& o = s.objs[idx];
+        const int at = (int)f.ent_lo.size();
+        if (first_leaf < 0) first_leaf = at;
+        switch (o.kind) {
+        case SPHERE:
+            f.ent_lo.push_back({o.c.x, o.c.y, o.c.z, o.r});
+            f.ent_hi.push_back({bits_f(o.id), 0, 0, bits_f(ENT_SPHERE)});
+            break;
+        case CUBE:
+            f.ent_lo.push_back({o.box.mn.x, o.box.mn.y, o.box.mn.z, bits_f(o.id)});
+            f.ent_hi.push_back({o.box.mx.x, o.box.mx.y, o.box.mx.z, bits_f(ENT_CUBE)});
+            break;
+        case TRI: {
+            const int ti = (int)f.tris.size() / RT_TRI_F4;
+            f.tris.push_back({o.p[0].x, o.p[0].y, o.p[0].z, 0});
+            f.tris.push_back({o.p[1].x, o.p[1].y, o.p[1].z, 0});
+            f.tris.push_back({o.p[2].x, o.p[2].y, o.p[2].z, 0});
+            f.tris.push_back({o.tc[0].x, o.tc[0].y, o.tc[1].x, o.tc[1].y});
+            f.tris.push_back({o.tc[2].x, o.tc[2].y, o.n[0].x, o.n[0].y});
+            f.tris.push_back({o.n[0].z, 0, 0, 0});
+            f.ent_lo.push_back({bits_f(ti), 0, 0, 0});
+            f.ent_hi.push_back({0, 0, 0, bits_f(ENT_TRI)});
+            break;
+        }
+        default: {   // MOVE / ROT / MESH chain = one instance
+            (void)top_level;
+            f.ent_lo.push_back({bits_f((int)pending.size()), 0, 0, 0});
+            f.ent_hi.push_back({0, 0, 0, bits_f(ENT_INSTANCE)});
+            pending.push_back(idx);
+            break;
+        }
+        }
+        return at;
+    }
+    void emit(int idx, bool top_level) {
+        const Obj& o = s.objs[idx];
+        if (o.kind != NODE) { emit_leaf(idx, top_level); return; }
+        const int at = (int)f.ent_lo.size();
+        f.ent_lo.push_back({o.box.mn.x, o.box.mn.y, o.box.mn.z, 0});
+        f.ent_hi.push_back({o.box.mx.x, o.box.mx.y, o.box.mx.z, bits_f(ENT_INNER)});
+        emit(o.left, top_level);
+        if (o.right != o.left) emit(o.right, top_level);
+        f.ent_lo[at].w = bits_f((int)f.ent_lo.size());
+    }
+    std::vector<int> pending;   // instance leaves of the top level, in instance-index order
+};
+
+void flatten(rt_scene& s) {
+    rt_scene_flat& f = s.flat;
+    f = rt_scene_flat();
+    Flattener fl{s, f};
+    fl.emit(s.root, true);
+    f.top_end = (int)f.ent_lo.size();
+    f.stale_entry = fl.first_leaf;
+    f.inst.resize(fl.pending.size() * RT_INST_F4);
+    for (size_t k = 0; k < fl.pending.size(); k++) {
+        int idx = fl.pending[k];
+        Vec3 offset{0, 0, 0}, pivot{0, 0, 0};
+        float has_move = 0, sin_t = 0, cos_t = 1;
+        int axis = -1;
+        const int id = s.objs[idx].id;
+        if (s.objs[idx].kind == MOVE) { offset = s.objs[idx].offset; has_move = 1; idx = s.objs[idx].target; }
+        if (s.objs[idx].kind == ROT) {
+            pivot = s.objs[idx].pivot; axis = s.objs[idx].axis; sin_t = s.objs[idx].sin_t; cos_t = s.objs[idx].cos_t;
+            idx = s.objs[idx].target;
+        }
+        const int begin = (int)f.ent_lo.size();
+        Flattener sub{s, f};
+        sub.emit(s.objs[idx].root, false);
+        const int end = (int)f.ent_lo.size();
+        f.inst[k * RT_INST_F4 + 0] = {offset.x, offset.y, offset.z, has_move};
+        f.inst[k * RT_INST_F4 + 1] = {pivot.x, pivot.y, pivot.z, bits_f(axis)};
+        f.inst[k * RT_INST_F4 + 2] = {sin_t, cos_t, bits_f(begin), bits_f(end)};
+        f.inst[k * RT_INST_F4 + 3] = {bits_f(id), bits_f(sub.first_leaf), 0, 0};
+    }
+    // texel pool: images, then the skybox; each padded by one zero row because uv == 1.0 indexes row h
+    // (Object.cpp:546-547 wrap; World.cpp:174-183 has no clamp)
+    for (const Image& im : s.images) {
+        ImageRec r{(uint32_t)f.texels.size(), (uint32_t)im.w, (uint32_t)im.h, 4};
+        f.texels.insert(f.texels.end(), im.px.begin(), im.px.end());
+        f.texels.resize(f.texels.size() + (size_t)im.w * 4 + 16, 0);
+        f.texels.resize((f.texels.size() + 15) & ~(size_t)15, 0);
+        f.images.push_back(r);
+    }
+    f.sky = {(uint32_t)f.texels.size(), (uint32_t)s.sky.w, (uint32_t)s.sky.h, 3};
+    f.texels.insert(f.texels.end(), s.sky.px.begin(), s.sky.px.end());
+    f.texels.resize(f.texels.size() + (size_t)s.sky.w * 3 + 16, 0);
+    f.texels.resize((f.texels.size() + 15) & ~(size_t)15, 0);
+    // objects by id
+    f.objects.assign((size_t)s.next_id * RT_OBJ_F4, F4{0, 0, 0, 0});
+    auto put_object = [&](int id, int material) {
+        const Mat& m = s.mats[material];
+        int tk = -1, img = -1;
+        Vec3 c1{0, 0, 0}, c2{0, 0, 0};
+        if (m.tex >= 0) { const Tex& t = s.texs[m.tex]; tk = t.kind; img = t.image; c1 = t.c1; c2 = t.c2; }
+        f.objects[(size_t)id * RT_OBJ_F4 + 0] = {bits_f(m.type), bits_f(tk), bits_f(img), 0};
+        f.objects[(size_t)id * RT_OBJ_F4 + 1] = {c1.x, c1.y, c1.z, 0};
+        f.objects[(size_t)id * RT_OBJ_F4 + 2] = {c2.x, c2.y, c2.z, 0};
+        f.objects[(size_t)id * RT_OBJ_F4 + 3] = {m.emit.x, m.emit.y, m.emit.z, 0};
+    };
+    auto mesh_of = [&](int idx) {
+        while (s.objs[idx].kind == MOVE || s.objs[idx].kind == ROT) idx = s.objs[idx].target;
+        return idx;
+    };
+    for (int idx : s.top) put_object(s.objs[idx].id, s.objs[mesh_of(idx)].material);
+    for (int idx : s.planes) {
+        put_object(s.objs[idx].id, s.objs[idx].material);
+        f.planes.push_back({s.objs[idx].y, bits_f(s.objs[idx].id), 0, 0});
+    }
+}
+
+int check_material(rt_scene* s, int material) {
+    if (!s) return fail(RT_E_INVALID, "null scene");
+    if (s->built) return fail(RT_E_INVALID, "scene is already built");
+    if (material < 0 || material >= (int)s->mats.size()) return fail(RT_E_INVALID, "material id out of range");
+    return RT_OK;
+}
+int add_top(rt_scene* s, Obj&& o) {
+    o.id = s->next_id++;
+    s->objs.push_back(std::move(o));
+    s->top.push_back((int)s->objs.size() - 1);
+    return s->objs.back().id;
+}
+
+// first-visit leaf numbering dumps, shared by the two dump entry points
+struct Dump {
+    const rt_scene& s;
+    std::vector<float> boxes;
+    std::vector<int> left, right, leaves, slot_of;
+    explicit Dump(const rt_scene& sc) : s(sc), slot_of(sc.objs.size(), -1) {}
+    int rec(int idx) {
+        const Obj& o = s.objs[idx];
+        if (o.kind == NODE) {
+            const int me = (int)left.size();
+            left.push_back(0);
+            right.push_back(0);
+            const float b[6] = {o.box.mn.x, o.box.mn.y, o.box.mn.z, o.box.mx.x, o.box.mx.y, o.box.mx.z};
+            boxes.insert(boxes.end(), b, b + 6);
+            const int l = rec(o.left), r = rec(o.right);
+            left[me] = l;
+            right[me] = r;
+            return me;
+        }
+        if (slot_of[idx] < 0) { slot_of[idx] = (int)leaves.size(); leaves.push_back(idx); }
+        return ~slot_of[idx];
+    }
+};
+
+}  // namespace
+
+// =================================================================================================== C ABI: scene
+extern "C" {
+
+void rt_config_defaults(rt_config* c) {
+    memset(c, 0, sizeof *c);
+    c->width = 1280; c->height = 720; c->samples_per_axis = 3; c->bounces = 3;
+    c->fov = 1.5f; c->skybox_brightness = 0.5f; c->dof_intensity = 0.05f; c->focus_distance = 10.0f;
+    c->device = 0; c->max_batch_paths = 0; c->tile_w = 64; c->tile_h = 64; c->flags = 0;
+}
+
+int rt_scene_create(rt_scene** out) {
+    if (!out) return fail(RT_E_INVALID, "null output pointer");
+    *out = new rt_scene();
+    return RT_OK;
+}
+void rt_scene_destroy(rt_scene* s) { delete s; }
+
+int rt_scene_add_texture_color(rt_scene* s, const float rgb[3]) {
+    if (!s || !rgb) return fail(RT_E_INVALID, "null argument");
+    s->texs.push_back({RT_TEX_COLOR, {rgb[0], rgb[1], rgb[2]}, {0, 0, 0}, -1});
+    return (int)s->texs.size() - 1;
+}
+int rt_scene_add_texture_checker(rt_scene* s, const float a[3], const float b[3]) {
+    if (!s || !a || !b) return fail(RT_E_INVALID, "null argument");
+    s->texs.push_back({RT_TEX_CHECKER, {a[0], a[1], a[2]}, {b[0], b[1], b[2]}, -1});
+    return (int)s->texs.size() - 1;
+}
+int rt_scene_add_texture_image(rt_scene* s, const uint8_t* rgba, int w, int h) {
+    if (!s || !rgba || w <= 0 || h <= 0) return fail(RT_E_INVALID, "bad image texture arguments");
+    Image im{std::vector<uint8_t>(rgba, rgba + (size_t)w * h * 4), w, h, 4};
+    s->images.push_back(std::move(im));
+    s->texs.push_back({RT_TEX_IMAGE, {0, 0, 0}, {0, 0, 0}, (int)s->images.size() - 1});
+    return (int)s->texs.size() - 1;
+}
+int rt_scene_add_texture_file(rt_scene* s, const char* path) {
+    if (!s || !path) return fail(RT_E_INVALID, "null argument");
+    std::vector<uint8_t> px;
+    int w, h, fc;
+    std::string err;
+    if (!load_png(path, 4, true, px, w, h, fc, err)) return fail(RT_E_IO, err);
+    // DataUtility.cpp:105-108 accepts 3- and 4-channel files only
+    if (fc != 3 && fc != 4) return fail(RT_E_IO, std::string("An image had ") + std::to_string(fc) + " channels: " + path);
+    return rt_scene_add_texture_image(s, px.data(), w, h);
+}
+int rt_scene_add_material(rt_scene* s, int type, int texture, const float emit[3]) {
+    if (!s) return fail(RT_E_INVALID, "null scene");
+    if (type < RT_MAT_NONE || type > RT_MAT_LIGHT) return fail(RT_E_INVALID, "unknown material type");
+    if (texture >= (int)s->texs.size()) return fail(RT_E_INVALID, "texture id out of range");
+    if ((type == RT_MAT_DIFFUSE || type == RT_MAT_METAL || type == RT_MAT_ISOTROPIC) && texture < 0)
+        return fail(RT_E_INVALID, "this material type needs a texture");
+    Vec3 e{0, 0, 0};
+    if (emit) e = {emit[0], emit[1], emit[2]};
+    s->mats.push_back({type, texture < 0 ? -1 : texture, e});
+    return (int)s->mats.size() - 1;
+}
+int rt_scene_add_sphere(rt_scene* s, const float c[3], float radius, int material) {
+    if (int rc = check_material(s, material)) return rc;
+    Obj o;
+    o.kind = SPHERE; o.c = {c[0], c[1], c[2]}; o.r = radius; o.material = material;
+    return add_top(s, std::move(o));
+}
+int rt_scene_add_cube_minmax(rt_scene* s, const float mn[3], const float mx[3], int material) {
+    if (int rc = check_material(s, material)) return rc;
+    Obj o;
+    o.kind = CUBE; o.box = {{mn[0], mn[1], mn[2]}, {mx[0], mx[1], mx[2]}}; o.material = material;
+    return add_top(s, std::move(o));
+}
+int rt_scene_add_cube_center(rt_scene* s, const float c[3], float half, int material) {   // Object.h:29
+    const float mn[3] = {c[0] - half, c[1] - half, c[2] - half}, mx[3] = {c[0] + half, c[1] + half, c[2] + half};
+    return rt_scene_add_cube_minmax(s, mn, mx, material);
+}
+int rt_scene_add_plane(rt_scene* s, float y, int material) {
+    if (int rc = check_material(s, material)) return rc;
+    Obj o;
+    o.kind = PLANE; o.y = y; o.material = material;
+    if (y == 0) o.y = 0.001f;   // Object.h:40
+    o.id = s->next_id++;
+    s->objs.push_back(o);
+    s->planes.push_back((int)s->objs.size() - 1);
+    return o.id;
+}
+int rt_scene_add_mesh(rt_scene* s, const float* verts8, int n_tri, float size, int material, int rot_axis, float degrees,
+                      int has_move, const float offset[3]) {
+    if (int rc = check_material(s, material)) return rc;
+    if (!verts8 || n_tri <= 0) return fail(RT_E_INVALID, "mesh has no triangles");
+    if (rot_axis < -1 || rot_axis > 2) return fail(RT_E_INVALID, "rotation axis must be -1, 0, 1 or 2");
+    const int id = s->next_id++;
+    Obj m;
+    m.kind = MESH; m.material = material; m.id = id; m.size = size;
+    m.verts.assign(verts8, verts8 + (size_t)n_tri * 24);
+    s->objs.push_back(std::move(m));
+    int cur = (int)s->objs.size() - 1;
+    if (rot_axis >= 0) {
+        Obj r;
+        r.kind = ROT; r.target = cur; r.axis = rot_axis; r.degrees = degrees; r.id = id;
+        s->objs.push_back(r);
+        cur = (int)s->objs.size() - 1;
+    }
+    if (has_move) {
+        Obj v;
+        v.kind = MOVE; v.target = cur; v.id = id;
+        if (offset) v.offset = {offset[0], offset[1], offset[2]};
+        s->objs.push_back(v);
+        cur = (int)s->objs.size() - 1;
+    }
+    s->top.push_back(cur);
+    return id;
+}
+int rt_scene_add_mesh_file(rt_scene* s, const char* path, float size, int material, int rot_axis, float degrees, int has_move,
+                           const float offset[3]) {
+    if (!path) return fail(RT_E_INVALID, "null path");
+    std::vector<float> v;
+    std::string err;
+    if (!load_obj(path, v, err)) return fail(RT_E_IO, err);
+    if (v.size() % 24 != 0 || v.empty()) return fail(RT_E_IO, std::string("Vertex count was not a multiple of 3: ") + path);
+    return rt_scene_add_mesh(s, v.data(), (int)v.size() / 24, size, material, rot_axis, degrees, has_move, offset);
+}
+int rt_scene_set_skybox(rt_scene* s, const uint8_t* rgb, int w, int h) {
+    if (!s || !rgb || w <= 0 || h <= 0) return fail(RT_E_INVALID, "bad skybox arguments");
+    if (s->built) return fail(RT_E_INVALID, "scene is already built");
+    s->sky = Image{std::vector<uint8_t>(rgb, rgb + (size_t)w * h * 3), w, h, 3};
+    return RT_OK;
+}
+int rt_scene_set_skybox_file(rt_scene* s, const char* path) {
+    if (!s || !path) return fail(RT_E_INVALID, "null argument");
+    std::vector<uint8_t> px;
+    int w, h, fc;
+    std::string err;
+    if (!load_png(path, 3, true, px, w, h, fc, err)) return fail(RT_E_IO, err);
+    if (fc != 3) return fail(RT_E_IO, "The skybox had " + std::to_string(fc) + " channels instead of 3.");   // DataUtility.cpp:24-27
+    return rt_scene_set_skybox(s, px.data(), w, h);
+}
+
+// World.cpp:15-32.  `time` only matters to the alternative scene of World.cpp:34-40, which the reference compiles out.
+int rt_scene_add_default_objects(rt_scene* s, const char* asset_dir, float time) {
+    (void)time;
+    if (!s || !asset_dir) return fail(RT_E_INVALID, "null argument");
+    const std::string dir = std::string(asset_dir) + "/src/stb_image/";
+    if (int rc = rt_scene_set_skybox_file(s, (dir + "skybox12.png").c_str())) return rc;   // World.cpp:49
+    auto diffuse = [&](int tex) { return rt_scene_add_material(s, RT_MAT_DIFFUSE, tex, nullptr); };
+    const float grey[3] = {0.4f, 0.4f, (float)0.4};
+    const float c6[3] = {6, 2, -9};
+    rt_scene_add_cube_center(s, c6, 2, diffuse(rt_scene_add_texture_color(s, grey)));
+    const float brown[3] = {0.6f, 0.3f, 0.2f}, white[3] = {1.0f, 1.0f, 1.0f};
+    const float c8[3] = {8, 2, -4};
+    rt_scene_add_sphere(s, c8, 2, diffuse(rt_scene_add_texture_checker(s, brown, white)));
+    const int tree_tex = rt_scene_add_texture_file(s, (dir + "tree_texture.png").c_str());
+    if (tree_tex < 0) return tree_tex;
+    const float up[3] = {0, 5, 0};
+    const int tree = rt_scene_add_mesh_file(s, (dir + "tree.obj").c_str(), 10, diffuse(tree_tex), 0, 90, 1, up);
+    if (tree < 0) return tree;
+    for (int i = 0; i < 15; i++) {
+        const float radius = std::sin(i * 78.0f) * 1.9f + 1.0f;
+        const float c[3] = {i * 2.5f + 10, radius, 15.0f * std::sin(i * 34.4f)};
+        // glm::sin(i) with an int argument is std::sin(int): evaluated in double, narrowed by the vec3 constructor
+        const float si = (float)std::sin((double)i);
+        const float col[3] = {0.5f + si * 0.5f, 0.5f + std::sin(i * 1.7f) * 0.5f, 0.5f + si * 0.5f};
+        rt_scene_add_sphere(s, c, radius, diffuse(rt_scene_add_texture_color(s, col)));
+    }
+    const float green[3] = {0.2f, 0.6f, 0.3f};   // World.cpp:17
+    rt_scene_add_plane(s, 0, rt_scene_add_material(s, RT_MAT_METAL, rt_scene_add_texture_checker(s, white, green), nullptr));
+    return RT_OK;
+}
+
+int rt_scene_build(rt_scene* s, uint32_t build_key) {
+    if (!s) return fail(RT_E_INVALID, "null scene");
+    if (s->built) return fail(RT_E_INVALID, "scene is already built");
+    if (s->top.empty()) return fail(RT_E_INVALID, "scene has no bounded objects");
+    if (s->sky.w <= 0) return fail(RT_E_INVALID, "scene has no skybox");
+    s->rng_key = build_key;
+    s->rng_ctr = 0;
+    // constructors in creation order: each mesh builds its triangle BVH when it is created (World.cpp:26), wrappers after it
+    const size_t n0 = s->objs.size();
+    for (size_t i = 0; i < n0; i++) {
+        if (s->objs[i].kind == MESH) finish_mesh(*s, (int)i);
+        else if (s->objs[i].kind == ROT) finish_rotation(*s, (int)i);
+    }
+    std::vector<int> list = s->top;
+    s->root = build_node(*s, list, 0, (int)list.size());   // World.cpp:44
+    flatten(*s);
+    s->built = true;
+    return RT_OK;
+}
+
+int rt_scene_dump_top(const rt_scene* s, int max_nodes, float* boxes6, int32_t* left, int32_t* right, int32_t* leaf_ids, int32_t* n_leaves) {
+    if (!s || !s->built) return fail(RT_E_INVALID, "scene is not built");
+    Dump d(*s);
+    d.rec(s->root);
+    const int n = (int)d.left.size();
+    if (n > max_nodes) return fail(RT_E_INVALID, "dump buffer too small");
+    memcpy(boxes6, d.boxes.data(), sizeof(float) * 6 * n);
+    memcpy(left, d.left.data(), sizeof(int) * n);
+    memcpy(right, d.right.data(), sizeof(int) * n);
+    for (size_t i = 0; i < d.leaves.size(); i++) leaf_ids[i] = s->objs[d.leaves[i]].id;
+    *n_leaves = (int)d.leaves.size();
+    return n;
+}
+static int find_top(const rt_scene* s, int object_id) {
+    for (int idx : s->top) if (s->objs[idx].id == object_id) return idx;
+    return -1;
+}
+int rt_scene_dump_mesh(const rt_scene* s, int object_id, int max_nodes, float* boxes6, int32_t* left, int32_t* right, int max_tris,
+                       float* tris24, int32_t* n_tris) {
+    if (!s || !s->built) return fail(RT_E_INVALID, "scene is not built");
+    int idx = find_top(s, object_id);
+    while (idx >= 0 && (s->objs[idx].kind == MOVE || s->objs[idx].kind == ROT)) idx = s->objs[idx].target;
+    if (idx < 0 || s->objs[idx].kind != MESH) return fail(RT_E_INVALID, "object is not a mesh");
+    Dump d(*s);
+    d.rec(s->objs[idx].root);
+    const int n = (int)d.left.size();
+    if (n > max_nodes || (int)d.leaves.size() > max_tris) return fail(RT_E_INVALID, "dump buffer too small");
+    memcpy(boxes6, d.boxes.data(), sizeof(float) * 6 * n);
+    memcpy(left, d.left.data(), sizeof(int) * n);
+    memcpy(right, d.right.data(), sizeof(int) * n);
+    for (size_t i = 0; i < d.leaves.size(); i++) {
+        const Obj& t = s->objs[d.leaves[i]];
+        for (int k = 0; k < 3; k++) {
+            float* r = tris24 + 24 * i + 8 * k;
+            r[0] = t.p[k].x; r[1] = t.p[k].y; r[2] = t.p[k].z; r[3] = t.tc[k].x; r[4] = t.tc[k].y;
+            r[5] = t.n[k].x; r[6] = t.n[k].y; r[7] = t.n[k].z;
+        }
+    }
+    *n_tris = (int)d.leaves.size();
+    return n;
+}
+int rt_scene_dump_objects(const rt_scene* s, int max_obj, float* out) {
+    if (!s || !s->built) return fail(RT_E_INVALID, "scene is not built");
+    int count = 0;
+    for (int pass = 0; pass < 2; pass++)
+        for (int idx : (pass == 0 ? s->top : s->planes)) {
+            const Obj& o = s->objs[idx];
+            if (o.id >= max_obj) return fail(RT_E_INVALID, "dump buffer too small");
+            float* r = out + 20 * o.id;
+            std::fill(r, r + 20, 0.0f);
+            int material = o.material;
+            if (o.kind == SPHERE) { r[0] = 0; r[1] = o.c.x; r[2] = o.c.y; r[3] = o.c.z; r[4] = o.r; }
+            else if (o.kind == CUBE) { r[0] = 1; r[1] = o.box.mn.x; r[2] = o.box.mn.y; r[3] = o.box.mn.z; r[4] = o.box.mx.x; r[5] = o.box.mx.y; r[6] = o.box.mx.z; }
+            else if (o.kind == PLANE) { r[0] = 4; r[1] = o.y; }
+            else {
+                r[0] = 3;
+                const Box3 b = box_of(*s, idx);
+                r[1] = b.mn.x; r[2] = b.mn.y; r[3] = b.mn.z; r[4] = b.mx.x; r[5] = b.mx.y; r[6] = b.mx.z;
+                int m = idx;
+                while (s->objs[m].kind == MOVE || s->objs[m].kind == ROT) m = s->objs[m].target;
+                material = s->objs[m].material;
+            }
+            const Mat& m = s->mats[material];
+            r[9] = (float)m.type;
+            if (m.tex < 0) r[10] = -1;
+            else {
+                const Tex& t = s->texs[m.tex];
+                r[10] = (float)t.kind;
+                if (t.kind != RT_TEX_IMAGE) { r[11] = t.c1.x; r[12] = t.c1.y; r[13] = t.c1.z; }
+                if (t.kind == RT_TEX_CHECKER) { r[14] = t.c2.x; r[15] = t.c2.y; r[16] = t.c2.z; }
+            }
+            r[17] = m.emit.x; r[18] = m.emit.y; r[19] = m.emit.z;
+            count++;
+        }
+    return count;
+}
+int rt_scene_dump_instance(const rt_scene* s, int object_id, float* out) {
+    if (!s || !s->built) return fail(RT_E_INVALID, "scene is not built");
+    int idx = find_top(s, object_id);
+    if (idx < 0) return fail(RT_E_INVALID, "no such object");
+    std::fill(out, out + 17, 0.0f);
+    out[8] = -1;
+    const Obj* o = &s->objs[idx];
+    if (o->kind == MOVE) { out[0] = o->offset.x; out[1] = o->offset.y; out[2] = o->offset.z; out[15] = 1; o = &s->objs[o->target]; }
+    if (o->kind == ROT) {
+        out[3] = o->pivot.x; out[4] = o->pivot.y; out[5] = o->pivot.z; out[6] = o->sin_t; out[7] = o->cos_t; out[8] = (float)o->axis;
+        out[9] = o->box.mn.x; out[10] = o->box.mn.y; out[11] = o->box.mn.z; out[12] = o->box.mx.x; out[13] = o->box.mx.y; out[14] = o->box.mx.z;
+        out[16] = 1;
+    }
+    return 1;
+}
+int rt_scene_flat_info(const rt_scene* s, int64_t out[7]) {
+    if (!s || !s->built) return fail(RT_E_INVALID, "scene is not built");
+    const rt_scene_flat& f = s->flat;
+    out[0] = (int64_t)f.ent_lo.size();
+    out[1] = (int64_t)f.tris.size() / RT_TRI_F4;
+    out[2] = (int64_t)f.inst.size() / RT_INST_F4;
+    out[3] = (int64_t)f.objects.size() / RT_OBJ_F4;
+    out[4] = (int64_t)f.planes.size();
+    out[5] = (int64_t)f.texels.size();
+    out[6] = (int64_t)(16 * (f.ent_lo.size() * 2 + f.tris.size() + f.inst.size() + f.objects.size() + f.planes.size()) + f.texels.size());
+    return RT_OK;
+}
+
+int rt_load_obj(const char* path, int max_verts, float* verts8) {
+    if (!path) return fail(RT_E_INVALID, "null path");
+    std::vector<float> v;
+    std::string err;
+    if (!load_obj(path, v, err)) return fail(RT_E_IO, err);
+    const int n = (int)v.size() / 8;
+    if (n > max_verts) return fail(RT_E_INVALID, "vertex buffer too small");
+    if (verts8) memcpy(verts8, v.data(), v.size() * sizeof(float));
+    return n;
+}
+int rt_load_png(const char* path, int channels, int flip, int64_t max_bytes, uint8_t* out, int32_t* w, int32_t* h, int32_t* file_channels) {
+    if (!path || !w || !h || !file_channels) return fail(RT_E_INVALID, "null argument");
+    std::vector<uint8_t> px;
+    std::string err;
+    int ww, hh, fc;
+    if (!load_png(path, channels, flip != 0, px, ww, hh, fc, err)) return fail(RT_E_IO, err);
+    *w = ww; *h = hh; *file_channels = fc;
+    if ((int64_t)px.size() > max_bytes) return fail(RT_E_INVALID, "pixel buffer too small");
+    if (out) memcpy(out, px.data(), px.size());
+    return (int)px.size();
+}
+
+// Camera::SetForwardVector (DataUtility.cpp:10-15): u and v are not normalised
+static void camera_basis(Vec3 look, float* cam12) {
+    const Vec3 f = normalize(look), u = cross(Vec3{0, 1, 0}, f), v = cross(f, u);
+    cam12[3] = f.x; cam12[4] = f.y; cam12[5] = f.z; cam12[6] = u.x; cam12[7] = u.y; cam12[8] = u.z; cam12[9] = v.x; cam12[10] = v.y; cam12[11] = v.z;
+}
+void rt_camera_look(const float pos[3], const float look[3], float cam12[12]) {
+    cam12[0] = pos[0]; cam12[1] = pos[1]; cam12[2] = pos[2];
+    camera_basis({look[0], look[1], look[2]}, cam12);
+}
+void rt_camera_input(float cam[12], float xrel, float yrel, int key_w, int key_a, int key_s, int key_d) {
+    Vec3 pos{cam[0], cam[1], cam[2]};
+    if (xrel != 0.0f || yrel != 0.0f) {   // App.cpp:98, MOUSE_SENSITIVITY = 0.001 (Constants.h:22)
+        const Vec3 f{cam[3], cam[4], cam[5]}, u{cam[6], cam[7], cam[8]}, v{cam[9], cam[10], cam[11]};
+        camera_basis(f - (u * xrel + v * yrel) * 0.001f, cam);
+    }
+    const float speed = 0.25f;            // MOVEMENT_SPEED (Constants.h:21), App.cpp:114-137
+    Vec3 du{cam[6], 0, cam[8]}, df{cam[3], 0, cam[5]};
+    if (key_d) pos = pos - du * speed;
+    if (key_a) pos = pos + du * speed;
+    if (key_w) pos = pos + df * speed;
+    if (key_s) pos = pos - df * speed;
+    cam[0] = pos.x; cam[1] = pos.y; cam[2] = pos.z;
+}
+
+}  // extern "C"

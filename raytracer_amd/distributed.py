@@ -1,0 +1,51 @@
+"""One frame across the GPUs of a node: image-space tiles per rank, tiles gathered to the display rank.
+
+Replaces the reference's 7-way split of the frame buffer across std::threads (FrameManager.cpp:17-21,80-82).  One process
+per GPU.  The scene is replicated; the frame is cut into tile_w x tile_h tiles numbered row-major and rank r renders
+tiles r, r+n, r+2n, ... (interleaved, so cheap sky tiles and expensive geometry tiles spread evenly).  Each rank's tiles
+are packed into one buffer of equal size on every rank; a single gather (RCCL over xGMI with the "nccl" backend, gloo
+for CPU rehearsals) brings them to the display rank, which scatters them into the [A,B,G,R] frame.  No other exchange
+happens: pixels are independent because every (pixel, sample) owns its RNG stream.
+"""
+import torch
+import torch.distributed as dist
+
+
+class TileRenderer:
+    """engine: raytracer_amd.Engine (or any object with tile_bytes / render / assemble and a cfg with width/height).
+    group: a torch.distributed process group or None for the default; world size 1 needs no process group at all."""
+
+    def __init__(self, engine, device, rank=0, world_size=1, group=None, display_rank=0):
+        self.e = engine
+        self.device = torch.device(device)
+        self.rank, self.world, self.group, self.display = rank, world_size, group, display_rank
+        W, H = engine.cfg.width, engine.cfg.height
+        self.frame = torch.zeros(H * W * 4, dtype=torch.uint8, device=self.device) if rank == display_rank or world_size == 1 else None
+        if world_size > 1:
+            self.nb = engine.tile_bytes(world_size)
+            self.mine = torch.zeros(self.nb, dtype=torch.uint8, device=self.device)
+            self.gathered = torch.zeros(self.nb * world_size, dtype=torch.uint8, device=self.device) if rank == display_rank else None
+
+    def _stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else None
+
+    def render_frame(self, seed):
+        """Enqueue one frame.  Returns the frame tensor (H*W*4 bytes) on the display rank, None elsewhere."""
+        st = self._stream()
+        if self.world == 1:
+            self.e.render(seed, 0, 1, self.frame.data_ptr(), st)
+            return self.frame
+        self.e.render(seed, self.rank, self.world, self.mine.data_ptr(), st)
+        if self.rank == self.display:
+            dist.gather(self.mine, list(self.gathered.chunk(self.world)), dst=self.display, group=self.group)
+            self.e.assemble(self.gathered.data_ptr(), self.world, self.frame.data_ptr(), st)
+            return self.frame
+        dist.gather(self.mine, None, dst=self.display, group=self.group)
+        return None
+
+    def frame_numpy(self):
+        if self.frame is None:
+            return None
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        return self.frame.cpu().numpy().reshape(self.e.cfg.height, self.e.cfg.width, 4)

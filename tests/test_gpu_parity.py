@@ -1,0 +1,312 @@
+"""GPU parity: the HIP engine, called through the C ABI, against
+  (1) the golden vectors written by the reference's own C++ (tests/golden, oracle/gen_golden.py), and
+  (2) the CPU oracle (oracle/rt_oracle.c) running the same portable sinf/atan2f as the kernels.
+
+Bars: primary-hit object ids, hit distances, ray counts, RNG draw counts and per-sample radiance are compared BIT FOR BIT
+with the oracle (portable math) — integer, index and float work alike.  Against the reference's golden frames, ids and
+distances are bit-exact; 8-bit colour may differ where libm's sinf/atan2f and the portable versions round differently
+(a skybox texel or a checker cell flips): tolerance stated in assert_frame_close.
+"""
+import numpy as np
+import pytest
+
+from conftest import assert_bits, build_table_scene, synthetic_tables
+
+pytestmark = pytest.mark.gpu
+
+CAM_POS, CAM_LOOK = (0.0, 3.0, -10.0), (0.0, 0.0, 1.0)
+
+
+def assert_frame_close(got, ref, what):
+    """8-bit frames: >= 99.9 % of bytes identical, no byte off by more than 2 on >= 99.99 % of bytes, PSNR >= 50 dB."""
+    assert got.shape == ref.shape
+    d = np.abs(got.astype(np.int32) - ref.astype(np.int32))
+    same = float((d == 0).mean())
+    within2 = float((d <= 2).mean())
+    mse = float((d.astype(np.float64) ** 2).mean())
+    psnr = 99.0 if mse == 0 else 10 * np.log10(255.0 ** 2 / mse)
+    assert same >= 0.999 and within2 >= 0.9999 and psnr >= 50.0, f"{what}: identical {same:.6f}, within2 {within2:.6f}, PSNR {psnr:.1f} dB"
+    return same, psnr
+
+
+@pytest.fixture(scope="module")
+def gpu_default(rt, build_key):
+    scene = rt.default_scene(build_key)
+    return scene
+
+
+def make_engine(rt, scene, W, H, S, B, cam=None, **kw):
+    e = rt.Engine(rt.default_config(width=W, height=H, samples_per_axis=S, bounces=B, **kw))
+    e.set_scene(scene)
+    e.set_camera(cam if cam is not None else rt.camera_look(CAM_POS, CAM_LOOK))
+    return e
+
+
+def test_device_math_matches_oracle(rt, orc, gpu_default):
+    e = make_engine(rt, gpu_default, 64, 64, 1, 1)
+    rng = np.random.default_rng(5)
+    x = np.concatenate([rng.uniform(-50, 50, 40000), rng.uniform(-1e5, 1e5, 20000), rng.uniform(-1e9, 1e9, 4000),
+                        rng.normal(size=20000) * 1e-3, [0.0, -0.0, 1e-30, -1e-30, np.inf, -np.inf, np.nan, 3.14159274, 1.57079637, 1e38]]).astype(np.float32)
+    y = rng.normal(size=len(x)).astype(np.float32)
+    y[:50] = 0.0
+    y[50:100] = -0.0
+    x[100:150] = 0.0
+    x[150:160] = -0.0
+    y[150:155] = 0.0
+    s, a = e.eval_math(x, y)
+    L = orc.lib()
+    s_ref = np.array([L.orc_pm_sinf(float(v)) for v in x], np.float32)
+    a_ref = np.array([L.orc_pm_atan2f(float(b), float(c)) for b, c in zip(y, x)], np.float32)
+    assert_bits(s, s_ref, "portable sinf")
+    assert_bits(a, a_ref, "portable atan2f")
+    # and they are good approximations of the functions the reference calls
+    fin = np.isfinite(x) & (np.abs(x) < 1e5)
+    assert np.max(np.abs(s[fin].astype(np.float64) - np.sin(x[fin].astype(np.float64)))) < 1e-7
+
+
+def test_device_rng_matches_golden(rt, golden, gpu_default):
+    e = make_engine(rt, gpu_default, 64, 64, 1, 1)
+    g = golden("rng")
+    keys = np.repeat(g["keys"], 16)
+    ctr = np.tile(np.arange(16, dtype=np.uint32), len(g["keys"]))
+    r, _ = e.eval_rng(keys, ctr)
+    assert_bits(r.reshape(len(g["keys"]), 16), g["rand31"], "rand31")
+    r2, ud = e.eval_rng(np.full(32, 0xDEADBEEF, np.uint32), np.arange(32, dtype=np.uint32))
+    assert_bits(ud, g["random_unit_distance"], "RandomUnitDistance")
+
+
+def test_trace_default_scene(rt, golden, oracle_default, gpu_default):
+    g = golden("trace_default")
+    e = make_engine(rt, gpu_default, 64, 64, 1, 1)
+    hit, rec = e.trace(g["rays_o"], g["rays_d"])
+    assert_bits(hit, g["hit"], "closest-hit object ids vs the reference")
+    assert_bits(rec[:, 0], g["rec"][:, 0], "HitInfo.distance vs the reference (stale values included)")
+    h2, r2 = oracle_default.trace(g["rays_o"], g["rays_d"])
+    m = hit >= 0
+    # point and normal bit for bit; uv of plane hits is never written by the reference
+    assert_bits(rec[m, 1:7], r2[m, 1:7], "hit point and normal vs the oracle")
+    tri = hit == 2
+    assert_bits(rec[tri, 7:], r2[tri, 7:], "triangle uv vs the oracle")
+    cube = hit == 0
+    assert_bits(rec[cube, 7:], r2[cube, 7:], "cube uv vs the oracle")
+    sph = m & ~tri & ~cube & (hit != 18)
+    assert_bits(rec[sph, 7:], r2[sph, 7:], "sphere uv vs the oracle (portable atan2f)")
+    # against the reference's libm atan2f the sphere uv may differ in the last place
+    assert np.max(np.abs(rec[sph, 7:] - g["rec"][sph, 7:])) < 1e-6
+
+
+def test_ray_color_default_scene(rt, golden, oracle_default, gpu_default):
+    g = golden("trace_default")
+    n = len(g["keys"])
+    e = make_engine(rt, gpu_default, 256, 256, 1, 4)
+    col = e.ray_color(g["rays_o"][:n], g["rays_d"][:n], 4, g["keys"])
+    ref = oracle_default.ray_color(g["rays_o"][:n], g["rays_d"][:n], 4, g["keys"])
+    assert_bits(col, ref, "GetRayColor vs the oracle")
+    # vs the reference's own floats: equal except where a libm/portable rounding difference moved a texel or a checker cell
+    same = np.all(col.view(np.uint32) == g["ray_color"].view(np.uint32), axis=1).mean()
+    assert same > 0.995, same
+
+
+@pytest.mark.parametrize("W,H,S,B", [(256, 144, 3, 3), (160, 90, 2, 8), (67, 45, 4, 0)])
+def test_render_small_frames_bit_exact(rt, oracle_default, gpu_default, W, H, S, B):
+    cam = rt.camera_look(CAM_POS, CAM_LOOK)
+    e = make_engine(rt, gpu_default, W, H, S, B, cam)
+    e.keep_samples(True)
+    frame = e.render_frame(11)
+    got = e.read_samples()
+    ref = oracle_default.render(cam, W, H, S, B, 11, threads=8, want=("radiance", "primary_id", "primary_t", "rng_draws", "rgba"))
+    assert_bits(got["primary_id"], ref["primary_id"], "primary ids")
+    assert_bits(got["primary_t"], ref["primary_t"], "primary distances")
+    assert_bits(got["rng_draws"], ref["rng_draws"], "RNG draws per sample")
+    assert_bits(got["radiance"], ref["radiance"], "per-sample radiance")
+    assert_bits(frame, ref["rgba"], "8-bit frame")
+    st = e.stats()
+    assert st["paths"] == W * H * S * S
+
+
+def test_c1_frame_vs_reference_golden(rt, golden, oracle_default, gpu_default):
+    """The reference's own constants (1280x720, 9 spp, 3 bounces): every primary-hit id equals the reference's."""
+    g = golden("frame_c1")
+    W, H, S, B = (int(v) for v in g["cfg"])
+    seed = int(g["seed"])
+    e = make_engine(rt, gpu_default, W, H, S, B, max_batch_paths=1 << 30)
+    e.keep_samples(True)
+    frame = e.render_frame(seed)
+    got = e.read_samples(want=("primary_id", "primary_t", "radiance", "rng_draws"))
+    assert_bits(got["primary_id"].astype(np.int8), g["primary_id"], "C1 primary ids vs the reference")
+    x0, y0, x1, y1 = (int(v) for v in g["crop"])
+    sel = (np.arange(y0, y1)[:, None] * W + np.arange(x0, x1)[None, :]).reshape(-1)
+    assert_bits(got["primary_t"][sel], g["crop_primary_t"], "C1 crop distances vs the reference")
+    assert_bits(got["rng_draws"][sel], g["crop_rng_draws"], "C1 crop RNG draws vs the reference")
+    same = np.all(got["radiance"][sel].view(np.uint32) == g["crop_radiance"].view(np.uint32), axis=2).mean()
+    assert same > 0.995, f"crop radiance identical for {same:.4f} of samples"
+    assert_frame_close(frame, g["rgba"], "C1 frame vs the reference")
+    # and bit-exact against the oracle running the kernels' own sinf/atan2f, on a band of rows
+    ref = oracle_default.render(rt.camera_look(CAM_POS, CAM_LOOK), W, H, S, B, seed, rect=(0, 300, W, 420), threads=8, want=("rgba", "radiance"))
+    assert_bits(frame[300:420], ref["rgba"], "C1 rows 300..420 vs the oracle")
+    band = (np.arange(300, 420)[:, None] * W + np.arange(W)[None, :]).reshape(-1)
+    assert_bits(got["radiance"][band], ref["radiance"], "C1 band radiance vs the oracle")
+
+
+def test_c2_crops_and_s0_ids(rt, golden, oracle_default, gpu_default):
+    """1920x1080, 64 spp, 8 bounces: golden crops through the window API, and sample (0,0) ids of every pixel."""
+    g = golden("frame_c2")
+    W, H, S, B = (int(v) for v in g["cfg"])
+    seed = int(g["seed"])
+    cam = rt.camera_look(CAM_POS, CAM_LOOK)
+    e = make_engine(rt, gpu_default, W, H, S, B)
+    e.keep_samples(True)
+    for i in range(3):
+        rect = tuple(int(v) for v in g[f"crop{i}"])
+        e.set_window(rect)
+        e.render(seed)
+        frame = e.read_frame()
+        got = e.read_samples()
+        assert_bits(got["primary_id"].astype(np.int8), g[f"crop{i}_primary_id"], f"C2 crop{i} ids vs the reference")
+        assert_bits(got["primary_t"], g[f"crop{i}_primary_t"], f"C2 crop{i} distances vs the reference")
+        assert_bits(got["rng_draws"].astype(np.uint16), g[f"crop{i}_rng_draws"], f"C2 crop{i} RNG draws vs the reference")
+        x0, y0, x1, y1 = rect
+        assert_frame_close(frame[y0:y1, x0:x1], g[f"crop{i}_rgba"], f"C2 crop{i} colour vs the reference")
+        ref = oracle_default.render(cam, W, H, S, B, seed, rect=rect, threads=8, want=("radiance", "rgba"))
+        assert_bits(got["radiance"], ref["radiance"], f"C2 crop{i} radiance vs the oracle")
+        assert_bits(frame[y0:y1, x0:x1], ref["rgba"], f"C2 crop{i} colour vs the oracle")
+    e.close()
+    e1 = make_engine(rt, gpu_default, W, H, 1, B, max_batch_paths=1 << 30)
+    e1.keep_samples(True)
+    e1.render(seed)
+    got = e1.read_samples(want=("primary_id", "primary_t"))
+    assert_bits(got["primary_id"].astype(np.int8).reshape(H, W), g["s0_primary_id"], "C2 sample-0 ids vs the reference, every pixel")
+    assert_bits(got["primary_t"].reshape(H, W)[::8], g["s0_primary_t_rows"], "C2 sample-0 distances vs the reference")
+
+
+def test_c2_thumbnail(rt, golden, gpu_default):
+    g = golden("frame_c2")
+    W, H, S, B = (int(v) for v in g["thumb_cfg"])
+    e = make_engine(rt, gpu_default, W, H, S, B)
+    e.keep_samples(True)
+    frame = e.render_frame(int(g["seed"]))
+    got = e.read_samples(want=("primary_id",))
+    assert_bits(got["primary_id"].astype(np.int8), g["thumb_primary_id"], "thumbnail ids vs the reference")
+    assert_frame_close(frame, g["thumb_rgba"], "thumbnail colour vs the reference")
+
+
+def test_custom_scene_all_materials(rt, orc, golden, assets):
+    """every material and texture kind, Y/Z-rotated and moved mesh instances, inverted-box spheres, two planes"""
+    g = golden("scene_custom")
+    key = int(g["build_key"])
+    args = (g["tex"], g["mat"], g["obj"], g["plane"], assets["verts"], assets["tex"], assets["sky"], key)
+    scene = build_table_scene(rt.Scene(), *args)
+    osc = build_table_scene(orc.Scene(orc.MATH_PORTABLE), *args)
+    for a, b, n in zip(scene.dump_top(), osc.dump_top(), ("boxes", "left", "right", "leaf")):
+        assert_bits(a, b, "custom BVH " + n)
+    W, H, S, B = (int(v) for v in g["cfg"])
+    cam = rt.camera_look(g["cam_pos"], g["cam_look"])
+    e = make_engine(rt, scene, W, H, S, B, cam)
+    e.keep_samples(True)
+    frame = e.render_frame(int(g["seed"]))
+    got = e.read_samples()
+    assert_bits(got["primary_id"].astype(np.int8), g["primary_id"], "custom ids vs the reference")
+    assert_bits(got["primary_t"], g["primary_t"], "custom distances vs the reference")
+    assert_frame_close(frame, g["rgba"], "custom colour vs the reference")
+    ref = osc.render(cam, W, H, S, B, int(g["seed"]), threads=8, want=("radiance", "rgba", "rng_draws"))
+    assert_bits(got["radiance"], ref["radiance"], "custom radiance vs the oracle")
+    assert_bits(got["rng_draws"], ref["rng_draws"], "custom RNG draws vs the oracle")
+    assert_bits(frame, ref["rgba"], "custom frame vs the oracle")
+
+
+def test_synthetic_scene(rt, orc, golden, assets):
+    """a scaled-down C3: 3000 spheres/boxes from the PCG32 stream, same BVH as the reference builds"""
+    g = golden("scene_synthetic")
+    n, key = int(g["n"]), int(g["build_key"])
+    obj, tex, mat = synthetic_tables(n)
+    plane = [[0.0, len(mat) - 1]]
+    scene = build_table_scene(rt.Scene(), tex, mat, obj, plane, None, None, assets["sky"], key)
+    top = scene.dump_top()
+    assert_bits(top[1], g["top_left"], "synthetic BVH left links vs the reference")
+    assert_bits(top[2], g["top_right"], "synthetic BVH right links vs the reference")
+    assert_bits(top[3], g["top_leaf_ids"], "synthetic BVH leaf order vs the reference")
+    W, H, S, B = (int(v) for v in g["cfg"])
+    cam = rt.camera_look((0.0, 20.0, -150.0), (0.0, 0.0, 1.0))
+    e = make_engine(rt, scene, W, H, S, B, cam)
+    e.keep_samples(True)
+    frame = e.render_frame(int(g["seed"]))
+    got = e.read_samples(want=("primary_id", "primary_t", "radiance"))
+    assert_bits(got["primary_id"].astype(np.int16), g["primary_id"], "synthetic ids vs the reference")
+    assert_bits(got["primary_t"].reshape(H, W, S * S)[::6], g["primary_t_rows"], "synthetic distances vs the reference")
+    assert_frame_close(frame, g["rgba"], "synthetic colour vs the reference")
+    osc = build_table_scene(orc.Scene(orc.MATH_PORTABLE), tex, mat, obj, plane, None, None, assets["sky"], key)
+    ref = osc.render(cam, W, H, S, B, int(g["seed"]), threads=8, want=("radiance", "rgba"))
+    assert_bits(got["radiance"], ref["radiance"], "synthetic radiance vs the oracle")
+    assert_bits(frame, ref["rgba"], "synthetic frame vs the oracle")
+
+
+def test_camera_path_last_frame(rt, golden, gpu_default):
+    g = golden("camera_path")
+    cam = rt.camera_look(CAM_POS, CAM_LOOK)
+    for f in range(240):
+        cam = rt.camera_input(cam, 3.0, 1.0, w=int(f < 120), d=int(f >= 120))
+        assert_bits(cam, g["cams"][f], f"camera after frame {f}")
+    W, H, S, B = (int(v) for v in g["last_cfg"])
+    e = make_engine(rt, gpu_default, W, H, S, B, cam)
+    e.keep_samples(True)
+    frame = e.render_frame(7)
+    got = e.read_samples(want=("primary_id",))
+    assert_bits(got["primary_id"].astype(np.int8), g["last_primary_id"], "moved-camera ids vs the reference")
+    assert_frame_close(frame, g["last_rgba"], "moved-camera colour vs the reference")
+
+
+def test_batching_tiles_and_ranks_do_not_change_pixels(rt, gpu_default):
+    """size-independent properties at a ragged size: batch size, tile size and the rank split leave every byte unchanged"""
+    import torch
+    W, H, S, B = 333, 187, 3, 5
+    base = make_engine(rt, gpu_default, W, H, S, B).render_frame(3)
+    small = make_engine(rt, gpu_default, W, H, S, B, max_batch_paths=50000).render_frame(3)
+    assert_bits(small, base, "small batches")
+    tiles = make_engine(rt, gpu_default, W, H, S, B, tile_w=16, tile_h=8, max_batch_paths=70000).render_frame(3)
+    assert_bits(tiles, base, "16x8 tiles")
+    for n_ranks in (2, 3, 8):
+        e = make_engine(rt, gpu_default, W, H, S, B, tile_w=32, tile_h=32)
+        nb = e.tile_bytes(n_ranks)
+        gathered = torch.zeros(n_ranks * nb, dtype=torch.uint8, device="cuda")
+        for r in range(n_ranks):
+            e.render(3, rank=r, n_ranks=n_ranks, d_out=gathered.data_ptr() + r * nb)
+        out = torch.zeros(H * W * 4, dtype=torch.uint8, device="cuda")
+        e.assemble(gathered.data_ptr(), n_ranks, d_out=out.data_ptr())
+        e.sync()
+        assert_bits(out.cpu().numpy().reshape(H, W, 4), base, f"{n_ranks}-rank tile split")
+
+
+def test_c2_full_frame_properties(rt, gpu_default):
+    """BASELINE's full size (1920x1080, 64 spp, 8 bounces): deterministic, alpha constant, windows agree with the frame"""
+    W, H, S, B = 1920, 1080, 8, 8
+    e = make_engine(rt, gpu_default, W, H, S, B)
+    a = e.render_frame(7)
+    st = e.stats()
+    b = e.render_frame(7)
+    assert_bits(a, b, "two renders of the same frame")
+    assert (a[..., 0] == 255).all()
+    assert st["paths"] == W * H * S * S and st["rays"] > st["paths"]
+    assert st["rays_at_depth"][0] == st["paths"] and all(x >= y for x, y in zip(st["rays_at_depth"][:9], st["rays_at_depth"][1:10]))
+    e2 = make_engine(rt, gpu_default, W, H, S, B)
+    e2.set_window((928, 508, 992, 540))
+    c = e2.render_frame(7)
+    assert_bits(c[508:540, 928:992], a[508:540, 928:992], "window vs full frame")
+    assert not c[:508].any()
+
+
+def test_error_behaviour(rt, gpu_default):
+    E = rt.engine
+    with pytest.raises(rt.RtError):
+        rt.Engine(rt.default_config(width=0))
+    e = rt.Engine(rt.default_config(width=32, height=32))
+    with pytest.raises(rt.RtError):
+        e.render(1)                      # no scene, no camera
+    e.set_scene(gpu_default)
+    e.set_camera(rt.camera_look(CAM_POS, CAM_LOOK))
+    with pytest.raises(rt.RtError):
+        e.render(1, rank=2, n_ranks=2)
+    with pytest.raises(rt.RtError):
+        e.set_window((0, 0, 33, 10))
+    with pytest.raises(rt.RtError):
+        e.read_samples()                 # not armed
+    assert E.lib().rt_last_error()
