@@ -196,8 +196,40 @@ def main():
     skyd /= np.linalg.norm(skyd, axis=1, keepdims=True).astype(np.float32)
     skyc = R.skybox(w, skyd)
     must("skybox", skyc, s.skybox_lookup(skyd))
+    # rays leaving the surface of every sphere (what bounce rays look like): origin on the surface, direction in the outer
+    # hemisphere.  For the BVH's leftmost leaf these exercise the stale-HitInfo quirk (Object.cpp:17-19 assigns a negative
+    # distance before rejecting; World.cpp:114 then compares the plane against it and the ray ends in the sky).
+    so, sd = [], []
+    for row in objs[:18]:
+        if int(row[0]) != 0:
+            continue
+        c, r = row[1:4], abs(row[4])
+        nrm = rng.normal(size=(400, 3))
+        nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+        dd = nrm + 0.9 * rng.normal(size=(400, 3)) / 1.7
+        dd[:100] = nrm[:100] * [1, 0.2, 1] + [0, -0.9, 0]          # a good share pointing at the floor
+        dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+        so.append((c + r * nrm * rng.choice([1.0, 1.0, 1.5], size=(400, 1))).astype(np.float32))
+        sd.append(dd.astype(np.float32))
+    so, sd = np.concatenate(so), np.concatenate(sd)
+    sd = R.normalize(sd)
+    shit, srec = R.trace(w, so, sd)
+    sh2, sr2 = s.trace(so, sd)
+    must("surface trace hit", shit, sh2)
+    pm = shit == 18
+    srec[pm, 7:] = 0
+    sr2[pm, 7:] = 0
+    must("surface trace rec", srec, sr2)
+    n_stale = int(((shit == -1) & (srec[:, 0] != np.finfo(np.float32).max)).sum())
+    print(f"  surface rays: {len(so)}, misses that carry a stale HitInfo.distance: {n_stale}")
+    if n_stale == 0:
+        raise SystemExit("the surface-ray fixture does not exercise the stale-HitInfo quirk")
+    skeys = rng.integers(0, 2**32, len(so), dtype=np.uint64).astype(np.uint32)
+    scol = R.ray_color(w, so, sd, 3, skeys)
+    must("surface ray_color", scol, s.ray_color(so, sd, 3, skeys))
     save("trace_default", rays_o=o, rays_d=d, hit=hit, rec=rec_cmp, keys=keys[:4000], ray_color_bounces=np.array(4), ray_color=col,
-         sky_dirs=skyd, sky_rgb=skyc)
+         sky_dirs=skyd, sky_rgb=skyc, surf_o=so, surf_d=sd, surf_hit=shit, surf_rec=srec, surf_keys=skeys,
+         surf_color_bounces=np.array(3), surf_color=scol)
 
     # ---------------------------------------------------------------- C1: the reference's own constants, whole frame
     ci, cf = R.constants()

@@ -95,6 +95,21 @@ def test_trace_default_scene(rt, golden, oracle_default, gpu_default):
     assert np.max(np.abs(rec[sph, 7:] - g["rec"][sph, 7:])) < 1e-6
 
 
+def test_surface_rays_and_stale_hitinfo(rt, golden, oracle_default, gpu_default):
+    """bounce-like rays from sphere surfaces, including the stale HitInfo.distance of the BVH's leftmost leaf"""
+    g = golden("trace_default")
+    e = make_engine(rt, gpu_default, 128, 128, 1, 3)
+    hit, rec = e.trace(g["surf_o"], g["surf_d"])
+    assert_bits(hit, g["surf_hit"], "surface-ray ids vs the reference")
+    assert_bits(rec[:, 0], g["surf_rec"][:, 0], "surface-ray HitInfo.distance vs the reference")
+    assert ((hit == -1) & (rec[:, 0] < 0)).sum() > 100
+    m = hit >= 0
+    assert_bits(rec[m, 1:7], g["surf_rec"][m, 1:7], "surface-ray hit point and normal vs the reference")
+    col = e.ray_color(g["surf_o"], g["surf_d"], int(g["surf_color_bounces"]), g["surf_keys"])
+    assert_bits(col, oracle_default.ray_color(g["surf_o"], g["surf_d"], int(g["surf_color_bounces"]), g["surf_keys"]), "GetRayColor vs the oracle")
+    assert np.all(col.view(np.uint32) == g["surf_color"].view(np.uint32), axis=1).mean() > 0.995
+
+
 def test_ray_color_default_scene(rt, golden, oracle_default, gpu_default):
     g = golden("trace_default")
     n = len(g["keys"])
