@@ -163,6 +163,11 @@ int rt_engine_kernel_times(rt_engine* e, double out2[2]);
 /* Device self-checks used by the tests: the portable sinf / atan2f and the RNG evaluated on the GPU. */
 int rt_engine_eval_math(rt_engine* e, int n, const float* x, const float* y, float* sin_x, float* atan2_yx);
 int rt_engine_eval_rng(rt_engine* e, int n, const uint32_t* key, const uint32_t* ctr, uint32_t* rand31, float* unit_distance);
+/* The slab test divides through a per-ray reciprocal with two FMA corrections instead of the hardware's IEEE sequence.
+ * This compares the two on the GPU: the n given pairs (a / b) plus threads x rounds x 4 generated pairs whose quotients sit
+ * next to rounding boundaries.  *mismatches = pairs whose bit patterns differ; first_bad4 = (a, b, got, IEEE). */
+int rt_engine_check_division(rt_engine* e, int n, const float* a, const float* b, uint32_t seed, int threads, int rounds,
+                             uint64_t* mismatches, float* first_bad4);
 
 #ifdef __cplusplus
 }

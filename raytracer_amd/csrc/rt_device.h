@@ -27,7 +27,8 @@ __device__ __forceinline__ V3 normalize(V3 v) { float s = 1.0f / sqrtf(dot(v, v)
 __device__ __forceinline__ float gmin(float x, float y) { return (y < x) ? y : x; }   // glm/detail/func_common.inl:20
 __device__ __forceinline__ float gmax(float x, float y) { return (x < y) ? y : x; }   // :29
 __device__ __forceinline__ float comp(V3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
-__device__ __forceinline__ void setc(V3& v, int i, float f) { if (i == 0) v.x = f; else if (i == 1) v.y = f; else v.z = f; }
+// selects, not indexed stores: a run-time index into a register-resident vector would push it out to scratch memory
+__device__ __forceinline__ void setc(V3& v, int i, float f) { v.x = i == 0 ? f : v.x; v.y = i == 1 ? f : v.y; v.z = i >= 2 ? f : v.z; }
 __device__ __forceinline__ V3 xyz(float4 f) { return mk(f.x, f.y, f.z); }
 
 // ---------------------------------------------------------------------------------------------------- RNG
@@ -123,11 +124,12 @@ __device__ inline float pm_atan2f(float y, float x) {
 
 // ---------------------------------------------------------------------------------------------------- scene view
 struct Scene {
-    const float4* ent_lo; const float4* ent_hi;
+    const float4* ent;   // 2 x float4 per entry: lo, hi
     const float4* tris; const float4* inst; const float4* objects; const float4* planes;
     const rt::ImageRec* images; const uint8_t* texels;
     uint32_t sky_off, sky_w, sky_h;
     int top_end, stale_entry, n_planes;
+    int n_entries, n_tris, fast_div_ok;
 };
 struct Ray { V3 o, d; };
 
@@ -201,9 +203,9 @@ __device__ __forceinline__ int image_index(const rt::ImageRec im, float u, float
 }
 // Triangle::Intersect (Object.cpp:498-550).  alpha_img >= 0: the material's image texture decides solidity
 // (DataUtility.cpp:123-127).  `wrote`: HitInfo.distance was assigned although the triangle was rejected by the cut-out.
-__device__ __forceinline__ bool tri_test(const Scene& sc, int ti, int alpha_img, const Ray& r, float& t, float& uo, float& vo, bool& wrote) {
+__device__ __forceinline__ bool tri_test(const Scene& sc, const float4* tris, int ti, int alpha_img, const Ray& r, float& t, float& uo, float& vo, bool& wrote) {
     const float EPSILON = 0.0000001f;
-    const float4* T = sc.tris + (size_t)ti * rt::RT_TRI_F4;
+    const float4* T = tris + (size_t)ti * rt::RT_TRI_F4;
     const V3 v0 = xyz(T[0]), v1 = xyz(T[1]), v2 = xyz(T[2]);
     wrote = false;
     const V3 edge1 = v1 - v0, edge2 = v2 - v0;
@@ -283,6 +285,50 @@ __device__ __forceinline__ void from_instance(const float4 i0, const float4 i1, 
     if (i0.w != 0.0f) point = point + xyz(i0);
 }
 
+// ---------------------------------------------------------------------------------------------------- exact division, cheaply
+// A slab test divides six differences by the three direction components of the SAME ray.  With y = RN(1/b) computed once
+// per ray by a true division, RN(a/b) is recovered from y by two residual corrections (Markstein's scheme: q ~ a*y,
+// r = a - b*q exactly by FMA, q += r*y), five ordinary instructions instead of the ~11 of the hardware's IEEE sequence.
+// The scheme is exact (a zero quotient possibly with the other sign, which no comparison can tell) while nothing over/underflows; `usable` below admits a ray
+// only if that holds for every box of the scene: |dir| components in [2^-20, 2^20], origin components 0 or in
+// [2^-50, 2^40] — the host checks the same of all box coordinates (Scene::fast_div_ok).  Other rays take true division.
+__device__ __forceinline__ float div_by(float a, float b, float y) {
+    float q = a * y;
+    float r = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(r, y, q);
+    r = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(r, y, q);
+}
+__device__ __forceinline__ bool mag_in(float v, float lo, float hi) { const float a = fabsf(v); return a >= lo && a <= hi; }
+__device__ __forceinline__ bool coord_ok(float v) { return v == 0.0f || mag_in(v, 8.8817841970012523e-16f, 1.099511627776e12f); }
+struct Recip { float x, y, z; bool usable; };
+__device__ __forceinline__ Recip make_recip(const Ray& r, bool scene_ok) {
+    Recip k;
+    k.usable = scene_ok && mag_in(r.d.x, 9.5367431640625e-07f, 1048576.0f) && mag_in(r.d.y, 9.5367431640625e-07f, 1048576.0f) &&
+               mag_in(r.d.z, 9.5367431640625e-07f, 1048576.0f) && coord_ok(r.o.x) && coord_ok(r.o.y) && coord_ok(r.o.z);
+    k.x = 1.0f / r.d.x; k.y = 1.0f / r.d.y; k.z = 1.0f / r.d.z;
+    return k;
+}
+// BoundingBox::DoesRayHit with the divisions done through the ray's reciprocals: same quotients, same decisions
+// Straight-line form: all six quotients, then the three rejection tests combined — no early exit, so the wave runs one
+// instruction stream with no exec-mask bookkeeping.  Rays admitted to this path produce finite quotients only, for
+// which max/min by comparison (glm) and the hardware max/min agree.
+__device__ __forceinline__ bool box_hit_recip(V3 mn, V3 mx, const Ray& r, const Recip& k) {
+    const bool px = r.d.x >= 0, py = r.d.y >= 0, pz = r.d.z >= 0;
+    const float txmin = div_by((px ? mn.x : mx.x) - r.o.x, r.d.x, k.x);
+    const float txmax = div_by((px ? mx.x : mn.x) - r.o.x, r.d.x, k.x);
+    const float tymin = div_by((py ? mn.y : mx.y) - r.o.y, r.d.y, k.y);
+    const float tymax = div_by((py ? mx.y : mn.y) - r.o.y, r.d.y, k.y);
+    const float tzmin = div_by((pz ? mn.z : mx.z) - r.o.z, r.d.z, k.z);
+    const float tzmax = div_by((pz ? mx.z : mn.z) - r.o.z, r.d.z, k.z);
+    const bool rej_xy = (txmin > tymax) | (tymin > txmax);
+    const float t1 = fmaxf(txmin, tymin), t2 = fminf(txmax, tymax);
+    const bool rej_z = (t1 > tzmax) | (tzmin > t2);
+    const float tmin = fmaxf(t1, tzmin), tmax = fminf(t2, tzmax);
+    const bool behind = (tmin < 0.0f) & (tmax < 0.0f);
+    return !(rej_xy | rej_z | behind);
+}
+
 // ---------------------------------------------------------------------------------------------------- closest hit
 // What World::GetRayColor learns from rootNode->Intersect plus the plane list (World.cpp:105-119).
 //   best >= 0: entry index of the winning leaf; best <= -2: plane -(best+2); best == -1: nothing hit.
@@ -290,50 +336,114 @@ __device__ __forceinline__ void from_instance(const float4 i0, const float4 i1, 
 //   leaf assigned before rejecting (Object.cpp:17-19, 534-550), which the plane is then compared against.
 struct Closest { float dist; int best; int inst; float u, v; bool hit; };
 
-__device__ inline void closest_hit(const Scene& sc, const Ray& ray, Closest& c) {
-    c.dist = FLT_MAX; c.best = -1; c.inst = -1; c.u = 0; c.v = 0; c.hit = false;
-    int i = 0, end = sc.top_end, resume = 0, inst = -1, stale = sc.stale_entry, alpha_img = -1;
-    Ray cur = ray;
+// Per-lane traversal state.  The lane holds the entry it stands on (lo, hi, kind) so that the wave can decide which
+// phase to run: lanes on inner nodes step together (box tests), lanes on leaves test primitives together.
+enum : int { K_END = -1 };
+struct Walker {
+    Ray top, cur;            // the ray as given, and in the current (instance) frame
+    Recip rc;
+    int i, end, resume, inst, stale, alpha_img, kind;
+    float4 lo, hi;
+    Closest c;
+    bool busy;
+};
+// entries (and, when staged, triangles) either in LDS or in global memory
+struct Store { const float4* ent; const float4* tris; };   // ent: lo/hi interleaved, 2 x float4 per entry
+
+__device__ __forceinline__ void walker_load(const Store& st, Walker& w) {
+    if (w.i < w.end) {
+        w.lo = st.ent[2 * w.i];
+        w.hi = st.ent[2 * w.i + 1];
+        w.kind = __float_as_int(w.hi.w);
+    } else w.kind = K_END;
+}
+__device__ __forceinline__ void walker_start(const Scene& sc, const Store& st, Walker& w, const Ray& ray) {
+    w.top = ray; w.cur = ray;
+    w.rc = make_recip(ray, sc.fast_div_ok != 0);
+    w.i = 0; w.end = sc.top_end; w.resume = 0; w.inst = -1; w.stale = sc.stale_entry; w.alpha_img = -1;
+    w.c.dist = FLT_MAX; w.c.best = -1; w.c.inst = -1; w.c.u = 0; w.c.v = 0; w.c.hit = false;
+    w.busy = true;
+    walker_load(st, w);
+}
+// BVH_Node::Intersect (Object.cpp:241-252) on an inner entry: into the left subtree, or past the whole subtree.
+// Called by the whole wave; `act` marks the lanes that stand on an inner entry.  The reciprocal path runs unmasked
+// (lanes that are not `act` compute on whatever they hold and discard it); lanes whose ray is not admitted to it are
+// rare and redo the test with true divisions under a wave-uniform branch.
+__device__ __forceinline__ void walker_inner(const Store& st, Walker& w, bool act) {
+    bool h = box_hit_recip(xyz(w.lo), xyz(w.hi), w.cur, w.rc);
+    const bool slow = act && !w.rc.usable;
+    if (__any(slow)) {
+        if (slow) h = box_hit(xyz(w.lo), xyz(w.hi), w.cur);
+    }
+    if (act) {
+        w.i = h ? w.i + 1 : __float_as_int(w.lo.w);
+        walker_load(st, w);
+    }
+}
+// one leaf-level action.  Returns true when the ray has finished (closest hit known, plane list merged).
+__device__ __forceinline__ bool walker_leaf(const Scene& sc, const Store& st, Walker& w) {
+    if (w.kind == K_END) {
+        if (w.inst >= 0) {   // PolygonMesh and its wrappers return to the top level
+            w.i = w.resume; w.end = sc.top_end; w.inst = -1; w.stale = sc.stale_entry; w.cur = w.top;
+            w.rc = make_recip(w.top, sc.fast_div_ok != 0);
+            walker_load(st, w);
+            return false;
+        }
+        for (int p = 0; p < sc.n_planes; p++) {   // YPlane::Intersect (Object.cpp:139-149), merged as World.cpp:110-118
+            const float t = -(w.top.o.y - sc.planes[p].x) / w.top.d.y;
+            if (t < 0.001f) continue;             // "t < 1e-3" against a double: the same floats pass
+            if (t < w.c.dist) { w.c.hit = true; w.c.dist = t; w.c.best = -(p + 2); w.c.inst = -1; }
+        }
+        w.busy = false;
+        return true;
+    }
+    if (w.kind == rt::ENT_INSTANCE) {
+        const int ii = __float_as_int(w.lo.x);
+        const float4* I = sc.inst + (size_t)ii * rt::RT_INST_F4;
+        const float4 i0 = I[0], i1 = I[1], i2 = I[2], i3 = I[3];
+        w.cur = to_instance(i0, i1, i2, w.top);
+        w.rc = make_recip(w.cur, sc.fast_div_ok != 0);
+        w.resume = w.i + 1;
+        w.stale = (w.i == sc.stale_entry) ? __float_as_int(i3.y) : -1;
+        w.inst = ii;
+        const float4 ob = sc.objects[(size_t)__float_as_int(i3.x) * rt::RT_OBJ_F4];
+        w.alpha_img = __float_as_int(ob.y) == 2 ? __float_as_int(ob.z) : -1;
+        w.i = __float_as_int(i2.z);
+        w.end = __float_as_int(i2.w);
+        walker_load(st, w);
+        return false;
+    }
+    float t = 0, u = 0, v = 0;
+    bool ok, wrote = false;
+    if (w.kind == rt::ENT_SPHERE) ok = sphere_test(xyz(w.lo), w.lo.w, w.cur, t, wrote);
+    else if (w.kind == rt::ENT_CUBE) { V3 n; ok = cube_test(xyz(w.lo), xyz(w.hi), w.cur, t, n); }
+    else ok = tri_test(sc, st.tris, __float_as_int(w.lo.x), w.alpha_img, w.cur, t, u, v, wrote);
+    if (ok) {
+        if (!w.c.hit || t < w.c.dist) { w.c.hit = true; w.c.dist = t; w.c.best = w.i; w.c.inst = w.inst; w.c.u = u; w.c.v = v; }
+    } else if (wrote && w.i == w.stale) w.c.dist = t;
+    w.i++;
+    walker_load(st, w);
+    return false;
+}
+// Run the lanes of a wave that are busy until all of them have finished.  Inner-node steps repeat while at least
+// `inner_quorum` lanes stand on inner nodes, so the (expensive) leaf code runs with many lanes enabled.
+// One round for a wave: box tests while at least `quorum` lanes stand on inner entries, then one step for everybody
+// (inner entries for the stragglers, a leaf-level action for the others).  `done` reports lanes whose ray finished.
+__device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Walker& w, int quorum) {
     for (;;) {
-        if (i >= end) {
-            if (inst < 0) break;
-            i = resume; end = sc.top_end; inst = -1; stale = sc.stale_entry; cur = ray;   // PolygonMesh / wrappers return
-            continue;
-        }
-        const float4 lo = sc.ent_lo[i], hi = sc.ent_hi[i];
-        const int kind = __float_as_int(hi.w);
-        if (kind == rt::ENT_INNER) {          // BVH_Node::Intersect (Object.cpp:241-252): left subtree, then right
-            i = box_hit(xyz(lo), xyz(hi), cur) ? i + 1 : __float_as_int(lo.w);
-            continue;
-        }
-        if (kind == rt::ENT_INSTANCE) {
-            const float4* I = sc.inst + (size_t)__float_as_int(lo.x) * rt::RT_INST_F4;
-            const float4 i0 = I[0], i1 = I[1], i2 = I[2], i3 = I[3];
-            cur = to_instance(i0, i1, i2, ray);
-            resume = i + 1;
-            stale = (i == sc.stale_entry) ? __float_as_int(i3.y) : -1;
-            inst = __float_as_int(lo.x);
-            const float4 ob = sc.objects[(size_t)__float_as_int(i3.x) * rt::RT_OBJ_F4];
-            alpha_img = __float_as_int(ob.y) == 2 ? __float_as_int(ob.z) : -1;
-            i = __float_as_int(i2.z);
-            end = __float_as_int(i2.w);
-            continue;
-        }
-        float t = 0, u = 0, v = 0;
-        bool ok, wrote = false;
-        if (kind == rt::ENT_SPHERE) ok = sphere_test(xyz(lo), lo.w, cur, t, wrote);
-        else if (kind == rt::ENT_CUBE) { V3 n; ok = cube_test(xyz(lo), xyz(hi), cur, t, n); }
-        else ok = tri_test(sc, __float_as_int(lo.x), alpha_img, cur, t, u, v, wrote);
-        if (ok) {
-            if (!c.hit || t < c.dist) { c.hit = true; c.dist = t; c.best = i; c.inst = inst; c.u = u; c.v = v; }
-        } else if (wrote && i == stale) c.dist = t;
-        i++;
+        const bool act = w.busy && w.kind == rt::ENT_INNER;
+        if (__popcll(__ballot(act)) < quorum) break;
+        walker_inner(st, w, act);
     }
-    for (int p = 0; p < sc.n_planes; p++) {   // YPlane::Intersect (Object.cpp:139-149), merged as World.cpp:110-118
-        const float t = -(ray.o.y - sc.planes[p].x) / ray.d.y;
-        if (t < 0.001f) continue;             // "t < 1e-3" against a double: the same floats pass
-        if (t < c.dist) { c.hit = true; c.dist = t; c.best = -(p + 2); c.inst = -1; }
-    }
+    const bool act = w.busy && w.kind == rt::ENT_INNER;
+    if (__any(act)) walker_inner(st, w, act);
+    bool done = false;
+    if (w.busy && !act) done = walker_leaf(sc, st, w);
+    return done;
+}
+// Run the busy lanes of a wave until all of them have finished.
+__device__ __forceinline__ void walk_wave_to_end(const Scene& sc, const Store& st, Walker& w) {
+    while (__any(w.busy)) walk_round(sc, st, w, 24);
 }
 
 struct Hit { V3 point, normal; float u, v; int object; };
@@ -348,7 +458,7 @@ __device__ inline void finalize_hit(const Scene& sc, const Ray& ray, const Close
         h.object = __float_as_int(pl.y);
         return;
     }
-    const float4 lo = sc.ent_lo[c.best], hi = sc.ent_hi[c.best];
+    const float4 lo = sc.ent[2 * c.best], hi = sc.ent[2 * c.best + 1];
     const int kind = __float_as_int(hi.w);
     if (kind == rt::ENT_SPHERE) {
         h.point = ray.o + ray.d * c.dist;

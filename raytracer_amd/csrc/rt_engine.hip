@@ -1,18 +1,22 @@
 // MI355X engine: wavefront-batched path tracing of the reference's per-pixel path.
 //
-//   bounce kernel, first pass : generate (camera ray + lens sample, World.cpp:68-88) -> intersect -> shade -> compact
-//   bounce kernel, later pass : read a compacted ray queue                            -> intersect -> shade -> compact
-//   resolve kernel            : per pixel, sum the samples in the reference's order, tone-map, pack [A,B,G,R]
+// One batch of paths (a path = one pixel sample) is advanced bounce by bounce; every pass is two kernels over a ray queue:
 //
-// A path is one pixel sample.  It owns a slot in the batch; its RNG stream is keyed by (frame seed, pixel, sample), so
-// the result of a slot does not depend on scheduling.  The recursion of World::GetRayColor (World.cpp:104-171) becomes
-// a loop over bounce kernels: each pass writes the surviving rays, compacted with a wave64 ballot + prefix count, into
-// the other queue.  The recursion multiplies colours on the way back (innermost first); to reproduce that rounding
-// order every bounce stores its (factor, texture colour) in a per-slot stack which the terminating pass unwinds.
+//   intersect : persistent waves pull rays from the queue (pass 0: generate them from the camera, World.cpp:68-88), walk
+//               the stackless two-level BVH with the scene staged in LDS, and refill finished lanes with new rays, so a
+//               long traversal does not idle the other 63 lanes.  Writes one 20-byte hit record per ray.
+//   shade     : one lane per ray: finish the hit (point, normal, uv), material switch, texture lookup, bounce sampling
+//               (World.cpp:121-170); survivors are compacted into the other queue with a wave64 ballot + prefix count;
+//               finished paths unwind their colour stack and store the sample's radiance.
+//   resolve   : per pixel, sum the samples in the reference's order, tone-map, pack [A,B,G,R] (World.cpp:94-100).
+//
+// A path owns a slot in the batch; its RNG stream is keyed by (frame seed, pixel, sample), so the result of a slot does
+// not depend on scheduling.  The recursion of World::GetRayColor multiplies colours on the way back (innermost first);
+// to reproduce that rounding order every bounce stores its (factor, texture colour) in a per-slot stack which the
+// terminating pass unwinds.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -26,6 +30,11 @@ using namespace rtd;
 
 namespace {
 
+constexpr int IBLOCK = 512;         // intersect: 8 waves per block; two blocks per CU, each with its own copy of the scene in LDS
+constexpr int REFILL_AT = 16;       // a wave fetches new rays once this many lanes are idle
+constexpr int CHUNK = 256;          // queue positions a wave reserves per atomic
+constexpr int INNER_QUORUM = 24;    // lanes on inner nodes needed to repeat the box-test phase
+
 struct Cam { V3 pos, fwd, u, v; };
 struct Cfg { int W, H, S, B; float fov, sky, dof, focus; };
 // which pixels a batch covers: pixels are enumerated tile by tile over the tiles this rank owns
@@ -37,14 +46,16 @@ struct Batch {
 };
 struct Queues {
     float4* a[2]; float4* b[2];      // ray records: a = (o.xyz, d.x), b = (d.y, d.z, slot, ctr | depth << 24)
-    uint32_t* counts;                // counts[k] = rays entering bounce pass k
+    float4* hit; int* hit_inst;      // hit records by queue position: (distance, best entry, u, v), instance
+    uint32_t* counts;                // counts[k] = rays entering pass k
+    uint32_t* cursors;               // cursors[k] = queue positions of pass k handed out to intersect waves so far
     float4* stack;                   // [depth][slot] = (texture colour rgb, factor)
     float4* radiance;                // [slot] = sample radiance
     int capacity;                    // slots
 };
 struct Debug { int32_t* primary_id; float* primary_t; uint32_t* rng_draws; const uint32_t* keys; };
 
-__device__ __forceinline__ bool pixel_of(const Batch& bt, const Cfg& g, int lp, int& px, int& py) {
+__device__ __forceinline__ bool pixel_of(const Batch& bt, int lp, int& px, int& py) {
     const int per_tile = bt.tile_w * bt.tile_h;
     const int t = lp / per_tile, in = lp - t * per_tile;
     const int tile = bt.rank + t * bt.n_ranks;
@@ -74,65 +85,122 @@ __device__ __forceinline__ Ray camera_ray(const Cam& cam, const Cfg& g, int px, 
     return r;
 }
 
-// One bounce pass.  FIRST: the lane's ray comes from the camera; otherwise from queue `qin`.
+// The ray at queue position `idx` of a pass.  FIRST: generated from the camera (slot = idx); otherwise read from queue
+// `qin`.  Returns false for a position that holds no ray (a pixel outside the frame in a partial tile).
 template <bool FIRST>
-__global__ __launch_bounds__(256) void bounce_kernel(Scene sc, Cam cam, Cfg g, Batch bt, Queues q, int pass, Debug dbg) {
+__device__ __forceinline__ bool fetch_ray(const Cam& cam, const Cfg& g, const Batch& bt, const Queues& q, int qin, const Debug& dbg,
+                                          uint32_t idx, Ray& ray, Rng& rng, uint32_t& slot, uint32_t& depth) {
+    const int spp = g.S * g.S;
+    if (FIRST) {
+        slot = idx; depth = 0;
+        const int lp = (int)(idx / (uint32_t)spp), s = (int)(idx - (uint32_t)lp * (uint32_t)spp);
+        int px, py;
+        if (!pixel_of(bt, bt.first_pixel + lp, px, py)) return false;
+        rng.key = sample_key(bt.seed, (uint32_t)(py * g.W + px), (uint32_t)s);
+        rng.ctr = 0;
+        ray = camera_ray(cam, g, px, py, s / g.S, s % g.S, rng);
+        return true;
+    }
+    const float4 a = q.a[qin][idx], b = q.b[qin][idx];
+    ray.o = mk(a.x, a.y, a.z); ray.d = mk(a.w, b.x, b.y);
+    slot = __float_as_uint(b.z);
+    const uint32_t cd = __float_as_uint(b.w);
+    rng.ctr = cd & 0xFFFFFFu; depth = cd >> 24;
+    if (dbg.keys) rng.key = dbg.keys[slot];
+    else {
+        const int lp = (int)(slot / (uint32_t)spp), s = (int)(slot - (uint32_t)lp * (uint32_t)spp);
+        int px = 0, py = 0;
+        pixel_of(bt, bt.first_pixel + lp, px, py);
+        rng.key = sample_key(bt.seed, (uint32_t)(py * g.W + px), (uint32_t)s);
+    }
+    return true;
+}
+
+// ---- intersect (World.cpp:105-119) ----------------------------------------------------------------------------------
+template <bool FIRST, bool STAGED>
+__global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cfg g, Batch bt, Queues q, int pass, Debug dbg) {
+    extern __shared__ float4 smem[];
+    Store st;
+    if (STAGED) {   // whole scene (entries + triangles) into LDS once per block; blocks are persistent
+        const int n_ent4 = 2 * sc.n_entries, n_tri4 = rt::RT_TRI_F4 * sc.n_tris;
+        for (int k = threadIdx.x; k < n_ent4; k += blockDim.x) smem[k] = sc.ent[k];
+        for (int k = threadIdx.x; k < n_tri4; k += blockDim.x) smem[n_ent4 + k] = sc.tris[k];
+        __syncthreads();
+        st.ent = smem; st.tris = smem + n_ent4;
+    } else { st.ent = sc.ent; st.tris = sc.tris; }
+    const int qin = (pass + 1) & 1;
+    const uint32_t n_in = FIRST ? (uint32_t)bt.n_pixels * (uint32_t)(g.S * g.S) : q.counts[pass];
+    uint32_t* cursor = &q.cursors[pass];
+    const int lane = (int)(threadIdx.x & 63u);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    Walker w;
+    w.busy = false; w.kind = K_END;
+    uint32_t my_idx = 0;
+    // the wave owns queue positions [mine, mine_end); it reserves CHUNK more with one atomic when they run out
+    uint32_t mine = 0, mine_end = 0;
+    bool drained = false;   // wave-uniform: every queue position has been handed out
+    for (;;) {
+        const unsigned long long idle = __ballot(!w.busy);
+        if (!drained && __popcll(idle) >= REFILL_AT) {
+            if (mine == mine_end) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(cursor, (uint32_t)CHUNK);
+                base = (uint32_t)__shfl((int)base, 0);
+                mine = base < n_in ? base : n_in;
+                mine_end = base + CHUNK < n_in ? base + CHUNK : n_in;
+            }
+            if (mine == mine_end) drained = true;
+            else {
+                const uint32_t idx = mine + (uint32_t)__popcll(idle & below);
+                if (!w.busy && idx < mine_end) {
+                    Ray ray; Rng rng; uint32_t slot, depth;
+                    if (fetch_ray<FIRST>(cam, g, bt, q, qin, dbg, idx, ray, rng, slot, depth)) {
+                        my_idx = idx;
+                        walker_start(sc, st, w, ray);
+                    }
+                }
+                const uint32_t took = (uint32_t)__popcll(idle);
+                mine = mine + took < mine_end ? mine + took : mine_end;
+            }
+        }
+        if (!__any(w.busy)) {
+            if (drained) break;
+            continue;
+        }
+        if (walk_round(sc, st, w, INNER_QUORUM)) {
+            q.hit[my_idx] = make_float4(w.c.dist, __int_as_float(w.c.best), w.c.u, w.c.v);
+            q.hit_inst[my_idx] = w.c.inst;
+        }
+    }
+}
+
+// ---- shade + compact (World.cpp:121-170) ------------------------------------------------------------------------------
+template <bool FIRST>
+__global__ __launch_bounds__(256) void shade_kernel(Scene sc, Cam cam, Cfg g, Batch bt, Queues q, int pass, Debug dbg) {
     const int qin = (pass + 1) & 1, qout = pass & 1;
     const uint32_t n_in = FIRST ? (uint32_t)bt.n_pixels * (uint32_t)(g.S * g.S) : q.counts[pass];
-    const uint32_t n_round = (n_in + 63u) & ~63u;   // whole waves stay together for the ballots below
+    const uint32_t n_round = (n_in + 63u) & ~63u;   // whole waves stay together for the ballot below
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x) {
-        bool live = i < n_in;
         Ray ray;
         Rng rng;
         uint32_t slot = 0, depth = 0;
         ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1); rng.key = 0; rng.ctr = 0;
-        if (live) {
-            if (FIRST) {
-                slot = i;
-                const int spp = g.S * g.S;
-                const int lp = (int)(i / (uint32_t)spp), s = (int)(i - (uint32_t)lp * (uint32_t)spp);
-                int px, py;
-                live = pixel_of(bt, g, bt.first_pixel + lp, px, py);
-                if (live) {
-                    rng.key = dbg.keys ? dbg.keys[slot] : sample_key(bt.seed, (uint32_t)(py * g.W + px), (uint32_t)s);
-                    ray = camera_ray(cam, g, px, py, s / g.S, s % g.S, rng);
-                }
-            } else {
-                const float4 a = q.a[qin][i], b = q.b[qin][i];
-                ray.o = mk(a.x, a.y, a.z); ray.d = mk(a.w, b.x, b.y);
-                slot = __float_as_uint(b.z);
-                const uint32_t cd = __float_as_uint(b.w);
-                rng.ctr = cd & 0xFFFFFFu; depth = cd >> 24;
-                if (dbg.keys) rng.key = dbg.keys[slot];
-                else {
-                    const int spp = g.S * g.S;
-                    const int lp = (int)(slot / (uint32_t)spp), s = (int)(slot - (uint32_t)lp * (uint32_t)spp);
-                    int px, py;
-                    pixel_of(bt, g, bt.first_pixel + lp, px, py);
-                    rng.key = sample_key(bt.seed, (uint32_t)(py * g.W + px), (uint32_t)s);
-                }
-            }
-        }
+        const bool live = i < n_in && fetch_ray<FIRST>(cam, g, bt, q, qin, dbg, i, ray, rng, slot, depth);
         bool alive = false;        // continues into the next pass
         Ray next = ray;
         if (live) {
-            // ---- intersect (World.cpp:105-119)
+            const float4 hr = q.hit[i];
             Closest c;
-            closest_hit(sc, ray, c);
+            c.dist = hr.x; c.best = __float_as_int(hr.y); c.u = hr.z; c.v = hr.w; c.inst = q.hit_inst[i]; c.hit = c.best != -1;
+            Hit h;
+            if (c.hit) finalize_hit(sc, ray, c, h);
             if (FIRST) {
                 if (dbg.primary_t) dbg.primary_t[slot] = c.dist;
-                if (dbg.primary_id) {
-                    int id = -1;
-                    if (c.hit) { Hit h0; finalize_hit(sc, ray, c, h0); id = h0.object; }
-                    dbg.primary_id[slot] = id;
-                }
+                if (dbg.primary_id) dbg.primary_id[slot] = c.hit ? h.object : -1;
             }
-            // ---- shade (World.cpp:121-170)
             V3 L = mk(0, 0, 0);
             if (!c.hit) L = skybox_pixel(sc, ray.d) * g.sky;
             else {
-                Hit h;
-                finalize_hit(sc, ray, c, h);
                 const float4* ob = sc.objects + (size_t)h.object * rt::RT_OBJ_F4;
                 const int mtype = __float_as_int(ob[0].x);
                 const int remaining = g.B - (int)depth;       // the recursion's bounceAmount
@@ -154,14 +222,14 @@ __global__ __launch_bounds__(256) void bounce_kernel(Scene sc, Cam cam, Cfg g, B
             if (!alive) {
                 // unwind the recursion: colour = (factor * child) * texture, innermost first (World.cpp:138,151,166)
                 for (int k = (int)depth - 1; k >= 0; k--) {
-                    const float4 st = q.stack[(size_t)k * q.capacity + slot];
-                    L = (L * st.w) * mk(st.x, st.y, st.z);
+                    const float4 sk = q.stack[(size_t)k * q.capacity + slot];
+                    L = (L * sk.w) * mk(sk.x, sk.y, sk.z);
                 }
                 q.radiance[slot] = make_float4(L.x, L.y, L.z, 0.0f);
                 if (dbg.rng_draws) dbg.rng_draws[slot] = rng.ctr;
             }
         }
-        // ---- compact: survivors of this wave take consecutive places in the outgoing queue
+        // compact: survivors of this wave take consecutive places in the outgoing queue
         const unsigned long long mask = __ballot(alive);
         if (mask) {
             const int lane = (int)(threadIdx.x & 63u);
@@ -178,14 +246,14 @@ __global__ __launch_bounds__(256) void bounce_kernel(Scene sc, Cam cam, Cfg g, B
     }
 }
 
-// World.cpp:94-100 + FrameManager.cpp:89-94.  (char)(c * 255): truncation, then the low byte.
+// ---- resolve: World.cpp:94-100 + FrameManager.cpp:89-94.  (char)(c * 255): truncation, then the low byte ---------------
 __device__ __forceinline__ uint32_t to_u8(float c) { return (uint32_t)(int)(c * 255) & 0xFFu; }
 __global__ __launch_bounds__(256) void resolve_kernel(Cfg g, Batch bt, const float4* radiance, uint8_t* out, int packed) {
     const int lp = blockIdx.x * blockDim.x + threadIdx.x;
     if (lp >= bt.n_pixels) return;
     int px, py;
     const int glp = bt.first_pixel + lp;
-    if (!pixel_of(bt, g, glp, px, py)) return;
+    if (!pixel_of(bt, glp, px, py)) return;
     const int spp = g.S * g.S;
     V3 color = mk(0, 0, 0);
     const float4* r = radiance + (size_t)lp * spp;
@@ -205,19 +273,27 @@ __global__ __launch_bounds__(256) void assemble_kernel(Cfg g, Batch bt, const ui
     Batch b = bt;
     b.rank = (int)(i / per_rank_pixels);
     int px, py;
-    if (!pixel_of(b, g, (int)(i - (long long)b.rank * per_rank_pixels), px, py)) return;
+    if (!pixel_of(b, (int)(i - (long long)b.rank * per_rank_pixels), px, py)) return;
     out[(size_t)py * g.W + px] = gathered[i];
 }
 
-// closest-hit queries for arbitrary rays
+// closest-hit queries for arbitrary rays (same walker, scene read from global memory)
 __global__ __launch_bounds__(256) void trace_kernel(Scene sc, int n, const float* o3, const float* d3, int32_t* hit_id, float* rec9) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    Store st;
+    st.ent = sc.ent; st.tris = sc.tris;
+    Walker w;
+    w.busy = false; w.kind = K_END;
     Ray r;
-    r.o = mk(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]);
-    r.d = mk(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]);
-    Closest c;
-    closest_hit(sc, r, c);
+    r.o = mk(0, 0, 0); r.d = mk(0, 0, 1);
+    if (i < n) {
+        r.o = mk(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]);
+        r.d = mk(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]);
+        walker_start(sc, st, w, r);
+    }
+    walk_wave_to_end(sc, st, w);
+    if (i >= n) return;
+    const Closest& c = w.c;
     float* q = rec9 + 9 * (size_t)i;
     q[0] = c.dist;
     if (!c.hit) { hit_id[i] = -1; for (int k = 1; k < 9; k++) q[k] = 0; return; }
@@ -246,6 +322,38 @@ __global__ void rng_kernel(int n, const uint32_t* key, const uint32_t* ctr, uint
     Rng g; g.key = key[i]; g.ctr = ctr[i];
     ud[i] = unit_distance(g);
 }
+// the reciprocal-based division against the hardware's IEEE division: explicit pairs, then `rounds` pseudo-random pairs
+// per thread biased towards quotients next to rounding boundaries; counts disagreements (bit patterns, NaN == NaN)
+__global__ void div_check_kernel(int n, const float* a, const float* b, uint32_t seed, int rounds, unsigned long long* mismatches, float* first_bad) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long bad = 0;
+    auto check = [&](float x, float y) {
+        if (!mag_in(y, 9.5367431640625e-07f, 1048576.0f)) return;
+        if (!(x == 0.0f || mag_in(x, 1.0e-24f, 2.0e12f))) return;
+        const float k = 1.0f / y;
+        const float q1 = div_by(x, y, k), q2 = x / y;
+        // a zero quotient may come out with the other sign (a = -0); no comparison of the slab test can tell
+        if (!(q1 == q2) && !(q1 != q1 && q2 != q2)) {
+            if (bad == 0 && atomicAdd(mismatches + 1, 1ull) == 0) { first_bad[0] = x; first_bad[1] = y; first_bad[2] = q1; first_bad[3] = q2; }
+            bad++;
+        }
+    };
+    if (i < n) check(a[i], b[i]);
+    uint32_t key = fmix32(seed ^ (uint32_t)i * 0x9E3779B9u);
+    for (int r = 0; r < rounds; r++) {
+        const uint32_t r1 = fmix32(key + 3u * (uint32_t)r), r2 = fmix32(key ^ (0x85EBCA6Bu * (uint32_t)(r + 1)));
+        // y: random mantissa, exponent in [-19, 1]; q: random mantissa; x = RN(y * q) nudged by -1..1 ulp: quotients that
+        // sit on or next to representable values and midpoints
+        const float y = __uint_as_float(((108u + (r1 >> 27) % 21u) << 23) | (r1 & 0x7FFFFFu)) * ((r2 & 1u) ? -1.0f : 1.0f);
+        const float qq = __uint_as_float(((100u + (r2 >> 26) % 56u) << 23) | ((r2 >> 1) & 0x7FFFFFu));
+        const float x0 = y * qq;
+        check(x0, y);
+        check(__uint_as_float(__float_as_uint(x0) + 1u), y);
+        check(__uint_as_float(__float_as_uint(x0) - 1u), y);
+        check(qq, y);
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
 
 int fail(int code, const std::string& msg) { rt::set_error(msg); return code; }
 #define HIP_TRY(expr)                                                                                          \
@@ -271,15 +379,16 @@ struct rt_engine {
     bool have_scene = false, have_camera = false;
     Cam cam{};
     std::vector<void*> scene_allocs;
+    size_t staged_bytes = 0;            // LDS the intersect kernel needs to hold the scene; 0 = read it from global memory
     Queues q{};
     int n_counts = 0;
     uint8_t* d_frame = nullptr;
     Debug dbg{nullptr, nullptr, nullptr, nullptr};
     bool debug_valid = false;
-    int grid_blocks = 0;
+    int n_cus = 0;
     int win[4] = {0, 0, 0, 0};          // x0, y0, width, height of the render window
     // statistics of the last render
-    std::vector<uint32_t> h_counts;     // per batch x (B + 2)
+    std::vector<uint32_t> h_counts;     // per batch: counts (B + 2), cursors (B + 2)
     uint32_t* d_counts_all = nullptr;
     int counts_capacity = 0, last_batches = 0;
     uint64_t last_paths = 0;
@@ -320,22 +429,37 @@ hipEvent_t next_event(rt_engine* e) {
     return e->ev[e->ev_used++];
 }
 
-// the bounce passes of one batch: pass 0 generates, passes 1..B read the queue the previous pass filled
+template <bool FIRST>
+void launch_intersect(rt_engine* e, hipStream_t st, const Cfg& g, const Batch& bt, const Queues& q, int pass) {
+    const int blocks = e->n_cus * 2;
+    if (e->staged_bytes)
+        hipLaunchKernelGGL((intersect_kernel<FIRST, true>), dim3(blocks), dim3(IBLOCK), e->staged_bytes, st, e->sc, e->cam, g, bt, q, pass, e->dbg);
+    else
+        hipLaunchKernelGGL((intersect_kernel<FIRST, false>), dim3(blocks), dim3(IBLOCK), 0, st, e->sc, e->cam, g, bt, q, pass, e->dbg);
+}
+
+// the passes of one batch: pass 0 generates its rays, passes 1..B read the queue the previous pass filled.  counts points
+// at 2 * (B + 2) zeroed words: ray counts, then intersect cursors.
 int run_passes(rt_engine* e, const Batch& bt, hipStream_t st, uint32_t* counts, bool first_from_queue, int bounces) {
     Queues q = e->q;
     q.counts = counts;
+    q.cursors = counts + e->n_counts;
     Cfg g = make_cfg(e->cfg);
     g.B = bounces;
+    const int shade_blocks = e->n_cus * 8;
     for (int pass = 0; pass <= bounces; pass++) {
+        const bool first = pass == 0 && !first_from_queue;
         if (e->time_kernels) (void)hipEventRecord(next_event(e), st);
-        if (pass == 0 && !first_from_queue) {
+        if (first) launch_intersect<true>(e, st, g, bt, q, pass);
+        else launch_intersect<false>(e, st, g, bt, q, pass);
+        if (e->time_kernels) (void)hipEventRecord(next_event(e), st);
+        if (first) {
             const uint32_t n = (uint32_t)bt.n_pixels * (uint32_t)(g.S * g.S);
-            const int blocks = (int)std::min<uint32_t>((n + 255u) / 256u, (uint32_t)e->grid_blocks);
-            hipLaunchKernelGGL(bounce_kernel<true>, dim3(blocks), dim3(256), 0, st, e->sc, e->cam, g, bt, q, pass, e->dbg);
+            const int blocks = (int)std::min<uint32_t>((n + 255u) / 256u, (uint32_t)shade_blocks);
+            hipLaunchKernelGGL(shade_kernel<true>, dim3(blocks), dim3(256), 0, st, e->sc, e->cam, g, bt, q, pass, e->dbg);
         } else {
-            hipLaunchKernelGGL(bounce_kernel<false>, dim3(e->grid_blocks), dim3(256), 0, st, e->sc, e->cam, g, bt, q, pass, e->dbg);
+            hipLaunchKernelGGL(shade_kernel<false>, dim3(shade_blocks), dim3(256), 0, st, e->sc, e->cam, g, bt, q, pass, e->dbg);
         }
-        if (e->time_kernels) (void)hipEventRecord(next_event(e), st);
     }
     HIP_TRY(hipGetLastError());
     return RT_OK;
@@ -359,25 +483,28 @@ int rt_engine_create(const rt_config* cfg, rt_engine** out) {
     if (e->cfg.tile_w <= 0) e->cfg.tile_w = 64;
     if (e->cfg.tile_h <= 0) e->cfg.tile_h = 64;
     const int spp = cfg->samples_per_axis * cfg->samples_per_axis;
-    long long want = e->cfg.max_batch_paths > 0 ? e->cfg.max_batch_paths : (1ll << 23);
-    // a batch holds whole pixels and at least one tile row of them
+    // default: up to 2^27 paths per batch (about 30 GB of queues at 8 bounces) — a 1080p, 64 spp frame is one batch, and
+    // every pass is then a single pair of launches with one short tail
+    long long want = e->cfg.max_batch_paths > 0 ? e->cfg.max_batch_paths : (1ll << 27);
     const long long min_paths = (long long)spp * 64;
     if (want < min_paths) want = min_paths;
     e->win[0] = 0; e->win[1] = 0; e->win[2] = cfg->width; e->win[3] = cfg->height;
     const long long frame_paths = (long long)tiles_x(e) * tiles_y(e) * e->cfg.tile_w * e->cfg.tile_h * spp;
     if (want > frame_paths) want = frame_paths;
-    const long long batch_pixels = want / spp;
+    const long long batch_pixels = want / spp;   // a batch holds whole pixels
     e->q.capacity = (int)(batch_pixels * spp);
     e->cfg.max_batch_paths = e->q.capacity;
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
-    e->grid_blocks = prop.multiProcessorCount * 8;
+    e->n_cus = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreate(&e->stream));
     const size_t cap = (size_t)e->q.capacity;
     for (int k = 0; k < 2; k++) {
         HIP_TRY(hipMalloc((void**)&e->q.a[k], cap * sizeof(float4)));
         HIP_TRY(hipMalloc((void**)&e->q.b[k], cap * sizeof(float4)));
     }
+    HIP_TRY(hipMalloc((void**)&e->q.hit, cap * sizeof(float4)));
+    HIP_TRY(hipMalloc((void**)&e->q.hit_inst, cap * sizeof(int)));
     HIP_TRY(hipMalloc((void**)&e->q.stack, cap * sizeof(float4) * (size_t)std::max(1, cfg->bounces)));
     HIP_TRY(hipMalloc((void**)&e->q.radiance, cap * sizeof(float4)));
     HIP_TRY(hipMalloc((void**)&e->d_frame, (size_t)cfg->width * cfg->height * 4));
@@ -393,6 +520,7 @@ void rt_engine_destroy(rt_engine* e) {
     (void)hipStreamSynchronize(e->stream);
     free_scene(e);
     for (int k = 0; k < 2; k++) { (void)hipFree(e->q.a[k]); (void)hipFree(e->q.b[k]); }
+    (void)hipFree(e->q.hit); (void)hipFree(e->q.hit_inst);
     (void)hipFree(e->q.stack); (void)hipFree(e->q.radiance); (void)hipFree(e->d_frame); (void)hipFree(e->d_counts_all);
     (void)hipFree(e->dbg.primary_id); (void)hipFree(e->dbg.primary_t); (void)hipFree(e->dbg.rng_draws);
     for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
@@ -414,13 +542,13 @@ int rt_engine_set_scene(rt_engine* e, const rt_scene* s) {
     HIP_TRY(hipStreamSynchronize(e->stream));
     free_scene(e);
     Scene sc{};
-    float4 *lo, *hi, *tris, *inst, *objects, *planes;
+    float4 *ent, *tris, *inst, *objects, *planes;
     rt::ImageRec* images;
     uint8_t* texels;
-    if (int rc = upload(&lo, f->ent_lo.data(), f->ent_lo.size() * 16)) return rc;
-    e->scene_allocs.push_back(lo);
-    if (int rc = upload(&hi, f->ent_hi.data(), f->ent_hi.size() * 16)) return rc;
-    e->scene_allocs.push_back(hi);
+    std::vector<rt::F4> inter(f->ent_lo.size() * 2);   // lo and hi of an entry side by side: one 32-byte fetch
+    for (size_t i = 0; i < f->ent_lo.size(); i++) { inter[2 * i] = f->ent_lo[i]; inter[2 * i + 1] = f->ent_hi[i]; }
+    if (int rc = upload(&ent, inter.data(), inter.size() * 16)) return rc;
+    e->scene_allocs.push_back(ent);
     if (int rc = upload(&tris, f->tris.data(), f->tris.size() * 16)) return rc;
     e->scene_allocs.push_back(tris);
     if (int rc = upload(&inst, f->inst.data(), f->inst.size() * 16)) return rc;
@@ -433,11 +561,19 @@ int rt_engine_set_scene(rt_engine* e, const rt_scene* s) {
     e->scene_allocs.push_back(images);
     if (int rc = upload(&texels, f->texels.data(), f->texels.size())) return rc;
     e->scene_allocs.push_back(texels);
-    sc.ent_lo = lo; sc.ent_hi = hi; sc.tris = tris; sc.inst = inst; sc.objects = objects; sc.planes = planes;
+    sc.ent = ent; sc.tris = tris; sc.inst = inst; sc.objects = objects; sc.planes = planes;
     sc.images = images; sc.texels = texels;
     sc.sky_off = f->sky.offset; sc.sky_w = f->sky.w; sc.sky_h = f->sky.h;
     sc.top_end = f->top_end; sc.stale_entry = f->stale_entry; sc.n_planes = (int)f->planes.size();
+    sc.n_entries = (int)f->ent_lo.size(); sc.n_tris = (int)f->tris.size() / rt::RT_TRI_F4; sc.fast_div_ok = f->fast_div_ok ? 1 : 0;
     e->sc = sc;
+    // stage the whole scene in LDS when two 1024-thread blocks per CU can each hold it (160 KiB per CU)
+    const size_t need = (inter.size() + f->tris.size()) * 16;
+    e->staged_bytes = need <= 80 * 1024 ? need : 0;
+    if (e->staged_bytes) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->staged_bytes));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->staged_bytes));
+    }
     e->have_scene = true;
     return RT_OK;
 }
@@ -476,12 +612,13 @@ int rt_engine_render(rt_engine* e, uint32_t seed, int rank, int n_ranks, uint8_t
     const long long my_pixels = (long long)tiles_per_rank(e, n_ranks) * per_tile;
     const int batch_pixels = e->q.capacity / spp;
     const int n_batches = (int)((my_pixels + batch_pixels - 1) / batch_pixels);
-    if (n_batches * e->n_counts > e->counts_capacity) {
+    const int per_batch = 2 * e->n_counts;
+    if (n_batches * per_batch > e->counts_capacity) {
         (void)hipFree(e->d_counts_all);
-        e->counts_capacity = n_batches * e->n_counts;
+        e->counts_capacity = n_batches * per_batch;
         HIP_TRY(hipMalloc((void**)&e->d_counts_all, sizeof(uint32_t) * (size_t)e->counts_capacity));
     }
-    HIP_TRY(hipMemsetAsync(e->d_counts_all, 0, sizeof(uint32_t) * (size_t)n_batches * e->n_counts, st));
+    HIP_TRY(hipMemsetAsync(e->d_counts_all, 0, sizeof(uint32_t) * (size_t)n_batches * per_batch, st));
     if (n_ranks > 1) HIP_TRY(hipMemsetAsync(out, 0, (size_t)my_pixels * 4, st));
     e->ev_used = 0;
     e->last_batches = n_batches;
@@ -499,7 +636,7 @@ int rt_engine_render(rt_engine* e, uint32_t seed, int rank, int n_ranks, uint8_t
         Batch bt = make_batch(e, rank, n_ranks, seed);
         bt.first_pixel = b * batch_pixels;
         bt.n_pixels = (int)std::min<long long>(batch_pixels, my_pixels - (long long)b * batch_pixels);
-        uint32_t* counts = e->d_counts_all + (size_t)b * e->n_counts;
+        uint32_t* counts = e->d_counts_all + (size_t)b * per_batch;
         if (int rc = run_passes(e, bt, st, counts, false, c.bounces)) return rc;
         hipLaunchKernelGGL(resolve_kernel, dim3((bt.n_pixels + 255) / 256), dim3(256), 0, st, g, bt, e->q.radiance, out, n_ranks > 1 ? 1 : 0);
     }
@@ -561,7 +698,8 @@ int rt_engine_read_samples(rt_engine* e, float* radiance3, int32_t* primary_id, 
     if (!e->debug_valid) return fail(RT_E_INVALID, "per-sample outputs need a single-rank render that fits one batch");
     const rt_config& c = e->cfg;
     const int spp = c.samples_per_axis * c.samples_per_axis;
-    const size_t slots = (size_t)e->q.capacity;
+    const int tx_n = tiles_x(e), per_tile = c.tile_w * c.tile_h, ww = e->win[2], wh = e->win[3];
+    const size_t slots = (size_t)tx_n * tiles_y(e) * per_tile * spp;
     // slots are enumerated tile by tile; hand them back in row-major pixel order
     std::vector<float4> rad;
     std::vector<int32_t> pid;
@@ -571,7 +709,6 @@ int rt_engine_read_samples(rt_engine* e, float* radiance3, int32_t* primary_id, 
     if (primary_id) { pid.resize(slots); HIP_TRY(hipMemcpy(pid.data(), e->dbg.primary_id, slots * 4, hipMemcpyDeviceToHost)); }
     if (primary_t) { pt.resize(slots); HIP_TRY(hipMemcpy(pt.data(), e->dbg.primary_t, slots * 4, hipMemcpyDeviceToHost)); }
     if (rng_draws) { draws.resize(slots); HIP_TRY(hipMemcpy(draws.data(), e->dbg.rng_draws, slots * 4, hipMemcpyDeviceToHost)); }
-    const int tx_n = tiles_x(e), per_tile = c.tile_w * c.tile_h, ww = e->win[2], wh = e->win[3];
     for (int py = 0; py < wh; py++)
         for (int px = 0; px < ww; px++) {
             const int tile = (py / c.tile_h) * tx_n + px / c.tile_w;
@@ -625,9 +762,10 @@ int rt_engine_ray_color(rt_engine* e, int n, const float* o3, const float* d3, i
     int rc = RT_OK;
     if ((rc = upload(&d_o, o3, (size_t)n * 12)) == RT_OK && (rc = upload(&d_d, d3, (size_t)n * 12)) == RT_OK &&
         (rc = upload(&d_keys, keys, (size_t)n * 4)) == RT_OK) {
-        if (hipMalloc((void**)&d_counts, sizeof(uint32_t) * 40) != hipSuccess) rc = fail(RT_E_NOMEM, "device allocation failed");
+        const size_t words = 2 * (size_t)e->n_counts;
+        if (hipMalloc((void**)&d_counts, sizeof(uint32_t) * words) != hipSuccess) rc = fail(RT_E_NOMEM, "device allocation failed");
         else {
-            (void)hipMemsetAsync(d_counts, 0, sizeof(uint32_t) * 40, e->stream);
+            (void)hipMemsetAsync(d_counts, 0, sizeof(uint32_t) * words, e->stream);
             // the rays enter pass 0 through queue (0+1)&1 = 1
             hipLaunchKernelGGL(load_rays_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, d_o, d_d, e->q.a[1], e->q.b[1], d_counts);
             const Debug saved = e->dbg;
@@ -658,12 +796,12 @@ int rt_engine_get_stats(rt_engine* e, rt_stats* out) {
     HIP_TRY(hipSetDevice(e->cfg.device));
     HIP_TRY(hipStreamSynchronize(e->stream));
     memset(out, 0, sizeof *out);
-    const int nb = e->last_batches, nc = e->n_counts;
+    const int nb = e->last_batches, nc = e->n_counts, per_batch = 2 * nc;
     if (nb <= 0) return RT_OK;
-    e->h_counts.resize((size_t)nb * nc);
-    HIP_TRY(hipMemcpy(e->h_counts.data(), e->d_counts_all, sizeof(uint32_t) * (size_t)nb * nc, hipMemcpyDeviceToHost));
+    e->h_counts.resize((size_t)nb * per_batch);
+    HIP_TRY(hipMemcpy(e->h_counts.data(), e->d_counts_all, sizeof(uint32_t) * (size_t)nb * per_batch, hipMemcpyDeviceToHost));
     for (int b = 0; b < nb; b++)
-        for (int k = 1; k < nc - 1 && k < 33; k++) out->rays_at_depth[k] += e->h_counts[(size_t)b * nc + k];
+        for (int k = 1; k < nc - 1 && k < 33; k++) out->rays_at_depth[k] += e->h_counts[(size_t)b * per_batch + k];
     out->paths = e->last_paths;
     out->rays_at_depth[0] = e->last_paths;
     for (int k = 0; k < 33; k++) out->rays += out->rays_at_depth[k];
@@ -720,6 +858,30 @@ int rt_engine_eval_rng(rt_engine* e, int n, const uint32_t* key, const uint32_t*
     HIP_TRY(hipMemcpy(r31, dr, (size_t)n * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(ud, du, (size_t)n * 4, hipMemcpyDeviceToHost));
     (void)hipFree(dk); (void)hipFree(dc); (void)hipFree(dr); (void)hipFree(du);
+    return RT_OK;
+}
+// The slab test's reciprocal-based division against the hardware's IEEE division: the n given pairs plus
+// threads x rounds x 4 generated pairs next to rounding boundaries.  out[0] = disagreeing pairs; first_bad4 = (a, b, got, want).
+int rt_engine_check_division(rt_engine* e, int n, const float* a, const float* b, uint32_t seed, int threads, int rounds,
+                             uint64_t* mismatches, float* first_bad4) {
+    if (!e || !mismatches || !first_bad4 || n < 0 || threads <= 0 || rounds < 0) return fail(RT_E_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    float *da = nullptr, *db = nullptr, *dbad;
+    unsigned long long* dm;
+    if (int rc = upload(&da, a, (size_t)n * 4)) return rc;
+    if (int rc = upload(&db, b, (size_t)n * 4)) return rc;
+    HIP_TRY(hipMalloc((void**)&dm, 16));
+    HIP_TRY(hipMalloc((void**)&dbad, 16));
+    HIP_TRY(hipMemset(dm, 0, 16));
+    HIP_TRY(hipMemset(dbad, 0, 16));
+    const int total = std::max(n, threads);
+    hipLaunchKernelGGL(div_check_kernel, dim3((total + 255) / 256), dim3(256), 0, e->stream, n, da, db, seed, rounds, dm, dbad);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    unsigned long long m[2];
+    HIP_TRY(hipMemcpy(m, dm, 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(first_bad4, dbad, 16, hipMemcpyDeviceToHost));
+    *mismatches = m[0];
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dm); (void)hipFree(dbad);
     return RT_OK;
 }
 

@@ -56,6 +56,7 @@ struct rt_scene_flat {
     std::vector<uint8_t> texels;             // all images then the skybox, each padded by one row
     rt::ImageRec sky{0, 0, 0, 0};
     int32_t top_end = 0, stale_entry = -1;
+    bool fast_div_ok = false;                // every box coordinate is 0 or has magnitude in [2^-50, 2^40] (see rt_device.h, div_by)
 };
 
 const rt_scene_flat* rt_scene_get_flat(const struct rt_scene* s);

@@ -260,6 +260,15 @@ void flatten(rt_scene& s) {
         f.inst[k * RT_INST_F4 + 2] = {sin_t, cos_t, bits_f(begin), bits_f(end)};
         f.inst[k * RT_INST_F4 + 3] = {bits_f(id), bits_f(sub.first_leaf), 0, 0};
     }
+    f.fast_div_ok = true;
+    for (size_t i = 0; i < f.ent_lo.size(); i++) {
+        if (bits_i(f.ent_hi[i].w) != ENT_INNER) continue;
+        const float c[6] = {f.ent_lo[i].x, f.ent_lo[i].y, f.ent_lo[i].z, f.ent_hi[i].x, f.ent_hi[i].y, f.ent_hi[i].z};
+        for (float v : c) {
+            const float a = std::fabs(v);
+            if (!(v == 0.0f || (a >= 8.8817841970012523e-16f && a <= 1.099511627776e12f))) f.fast_div_ok = false;
+        }
+    }
     // texel pool: images, then the skybox; each padded by one zero row because uv == 1.0 indexes row h
     // (Object.cpp:546-547 wrap; World.cpp:174-183 has no clamp)
     for (const Image& im : s.images) {

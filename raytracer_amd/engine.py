@@ -91,6 +91,7 @@ SIGNATURES = {
     "rt_engine_kernel_times": (C.c_int, [_V, f64p]),
     "rt_engine_eval_math": (C.c_int, [_V, C.c_int, f32p, f32p, f32p, f32p]),
     "rt_engine_eval_rng": (C.c_int, [_V, C.c_int, u32p, u32p, u32p, f32p]),
+    "rt_engine_check_division": (C.c_int, [_V, C.c_int, f32p, f32p, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint64), f32p]),
 }
 
 _L = None
@@ -396,6 +397,15 @@ class Engine:
         a = np.zeros_like(x)
         _check(self.L.rt_engine_eval_math(self.h, len(x), x, y, s, a))
         return s, a
+
+    def check_division(self, a, b, seed=1, threads=1 << 20, rounds=256):
+        """(mismatching pairs, first mismatch) of the reciprocal-based division vs IEEE division on the GPU"""
+        a = np.ascontiguousarray(a, np.float32)
+        b = np.ascontiguousarray(b, np.float32)
+        m = C.c_uint64(0)
+        bad = np.zeros(4, np.float32)
+        _check(self.L.rt_engine_check_division(self.h, len(a), a, b, seed, threads, rounds, C.byref(m), bad))
+        return int(m.value), bad
 
     def eval_rng(self, key, ctr):
         key = np.ascontiguousarray(key, np.uint32)

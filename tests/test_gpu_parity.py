@@ -64,6 +64,21 @@ def test_device_math_matches_oracle(rt, orc, gpu_default):
     assert np.max(np.abs(s[fin].astype(np.float64) - np.sin(x[fin].astype(np.float64)))) < 1e-7
 
 
+def test_reciprocal_division_is_ieee_division(rt, gpu_default):
+    """the slab test's a/b through the per-ray reciprocal must give the bits of a true division: explicit awkward pairs
+    plus ~4e9 generated pairs whose quotients sit on or next to representable values and rounding midpoints"""
+    e = make_engine(rt, gpu_default, 64, 64, 1, 1)
+    rng = np.random.default_rng(17)
+    n = 1 << 20
+    b = (rng.choice([-1.0, 1.0], n) * np.exp2(rng.uniform(-19.9, 0.1, n))).astype(np.float32)
+    a = (rng.normal(size=n) * np.exp2(rng.uniform(-30, 38, n))).astype(np.float32)
+    a[:4096] = 0.0
+    a[4096:8192] = -0.0
+    a[8192:16384] = (b[8192:16384].astype(np.float64) * rng.integers(1, 1 << 24, 8192)).astype(np.float32)   # exact quotients
+    bad, first = e.check_division(a, b, seed=5, threads=1 << 22, rounds=256)
+    assert bad == 0, f"{bad} quotients differ, first (a, b, got, want) = {first}"
+
+
 def test_device_rng_matches_golden(rt, golden, gpu_default):
     e = make_engine(rt, gpu_default, 64, 64, 1, 1)
     g = golden("rng")
