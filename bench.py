@@ -29,17 +29,24 @@ WORKLOADS = {
     "c2": ("default scene 1920x1080, 64 spp, 8 bounces", 1920, 1080, 8, 8),
     "c3": ("synthetic 100k sphere/box scene 3840x2160, 256 spp, 8 bounces", 3840, 2160, 16, 8),
 }
-# FLOPs the reference algorithm spends per counted event (sqrt and divide count 1, compares and libm calls excluded)
-FLOP_WEIGHTS = {"aabb": 16, "sph_test": 17, "sph_hit": 25, "cube_test": 12, "cube_hit": 21, "plane_test": 3, "plane_hit": 6,
-                "tri_test": 52, "tri_uv": 64, "inst_enter": 21, "inst_hit": 21, "samples": 45, "shade": 30}
-# bytes the reference algorithm touches per counted event with the SoA scene layout: 32 B per node visit, 16 B per sphere,
-# 24 B per cube, 36 B per triangle (+36 B on the uv path, +1 texel), 96 B of ray state per ray, 16 B hit record per ray
-BYTE_WEIGHTS = {"aabb": 32, "sph_test": 16, "cube_test": 24, "tri_test": 36, "tri_uv": 40, "rays": 112}
-PEAK_FP32_TFLOPS = 157.3     # MI355X vector FP32 (packed FMA); unfused, unpacked code tops out at 1/4 of it
+# FLOPs the reference algorithm spends per counted event (sqrt and divide count 1, compares and libm calls excluded).
+# The events of the closest-hit query (and, for primary rays, camera-ray generation) are the work of intersect_kernel,
+# the dominant kernel; finishing the hit and the material switch belong to shade_kernel.
+FLOP_INTERSECT = {"aabb": 16, "sph_test": 17, "cube_test": 12, "plane_test": 3, "tri_test": 52, "tri_uv": 64, "inst_enter": 21,
+                  "samples": 45}
+FLOP_SHADE = {"sph_hit": 25, "cube_hit": 21, "plane_hit": 6, "inst_hit": 21, "shade": 30}
+# bytes of scene data the reference algorithm touches per counted event: 32 B per node visit, 16 B per sphere, 24 B per
+# cube, 36 B per triangle (+40 B on the uv path).  The engine serves them from its LDS copy of the scene when it fits.
+SCENE_BYTE_WEIGHTS = {"aabb": 32, "sph_test": 16, "cube_test": 24, "tri_test": 36, "tri_uv": 40}
+# bytes intersect_kernel streams through HBM per ray: 32 B ray record read (bounce rays; primary rays are generated in
+# registers) and 20 B hit record written
+RAY_READ_BYTES, HIT_WRITE_BYTES = 32, 20
+PEAK_FP32_TFLOPS = 157.3     # MI355X vector FP32 with packed FMA; unfused scalar-per-lane code can reach 1/4 of it
 PEAK_HBM_GBS = 8000.0
-# measured by the oracle's counters on the C2 workload; used when the CPU leg is skipped
-FALLBACK_FLOP_PER_RAY = {"c1": 640.0, "c2": 640.0, "c3": 1500.0}
-FALLBACK_BYTE_PER_RAY = {"c1": 1100.0, "c2": 1100.0, "c3": 2500.0}
+# per-ray figures of the reference algorithm measured by the oracle's event counters over the CPU sample of each workload;
+# used when the CPU leg is skipped (--no-cpu-baseline, N > 1)
+FALLBACK_FLOP_PER_RAY = {"c1": 985.0, "c2": 985.0, "c3": 1500.0}
+FALLBACK_SCENE_BYTE_PER_RAY = {"c1": 1480.0, "c2": 1480.0, "c3": 2500.0}
 
 
 def build_scene(rt, workload):
@@ -69,23 +76,26 @@ def cpu_baseline(workload, W, H, S, B, threads):
         obj, tex_t, mat_t = synthetic_tables(100000)
         build_from_tables(s, tex_t, mat_t, obj, [[0.0, len(mat_t) - 1]], sky, BUILD_KEY + 2)
         cam = O.camera((0.0, 20.0, -150.0), (0.0, 0.0, 1.0))
-    n_strips, rows = {"c1": (12, 8), "c2": (17, 4), "c3": (4, 1)}[workload]
+    # sized for roughly 10-30 s on 16 host threads: the whole frame for c1/c2, a few row segments for c3
+    n_strips, rows = {"c1": (1, H), "c2": (1, H), "c3": (4, 1)}[workload]
     s.counters(reset=True)
     t0 = time.perf_counter()
     px = 0
     for k in range(n_strips):
-        y0 = int((k + 0.5) * H / n_strips)
+        y0 = int((k + 0.5) * H / n_strips) if rows < H else 0
         x1 = W if workload != "c3" else W // 16
         s.render(cam, W, H, S, B, SEED, rect=(0, y0, x1, min(H, y0 + rows)), threads=threads, want=("rgba",))
         px += x1 * (min(H, y0 + rows) - y0)
     dt = time.perf_counter() - t0
     c = s.counters()
-    flops = sum(FLOP_WEIGHTS[k] * c[k] for k in FLOP_WEIGHTS)
-    nbytes = sum(BYTE_WEIGHTS[k] * c[k] for k in BYTE_WEIGHTS)
+    flops = sum(FLOP_INTERSECT[k] * c[k] for k in FLOP_INTERSECT)
+    flops_shade = sum(FLOP_SHADE[k] * c[k] for k in FLOP_SHADE)
+    nbytes = sum(SCENE_BYTE_WEIGHTS[k] * c[k] for k in SCENE_BYTE_WEIGHTS)
     return {"value": c["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
             "sample": f"{n_strips} strips x {rows} rows = {px} pixels of the {W}x{H} frame, all {S * S} spp and {B} bounces, "
                       f"{c['rays']} rays in {dt:.1f} s; contiguous pixel ranges per thread as FrameManager.cpp:80-82",
-            "flop_per_ray": flops / c["rays"], "byte_per_ray": nbytes / c["rays"], "rays_per_sample": c["rays"] / c["samples"]}
+            "intersect_flop_per_ray": flops / c["rays"], "shade_flop_per_ray": flops_shade / c["rays"],
+            "scene_byte_per_ray": nbytes / c["rays"], "rays_per_sample": c["rays"] / c["samples"]}
 
 
 def main():
@@ -158,14 +168,16 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             threads = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))
             cpu = cpu_baseline(args.workload, W, H, S, B, threads)
-        flop_per_ray = cpu["flop_per_ray"] if cpu else FALLBACK_FLOP_PER_RAY[args.workload]
-        byte_per_ray = cpu["byte_per_ray"] if cpu else FALLBACK_BYTE_PER_RAY[args.workload]
+        flop_per_ray = cpu["intersect_flop_per_ray"] if cpu else FALLBACK_FLOP_PER_RAY[args.workload]
+        scene_byte_per_ray = cpu["scene_byte_per_ray"] if cpu else FALLBACK_SCENE_BYTE_PER_RAY[args.workload]
         value = rays_frame * args.steps / dt / 1e6
-        # dominant kernel = the bounce kernel (intersect + shade + compact); its launches of one rank, timed with HIP events
+        # dominant kernel = intersect_kernel (one launch per bounce level); the launches of the last timed frame on the
+        # slowest rank, measured with HIP events on the render stream; every step renders the same frame
         kern_s = float(kt[0]) / 1e3
-        rays_rank0 = st["rays"] * args.steps
+        rays_rank0 = st["rays"]
         ach_tflops = flop_per_ray * rays_rank0 / kern_s / 1e12 if kern_s > 0 else None
-        ach_gbs = byte_per_ray * rays_rank0 / kern_s / 1e9 if kern_s > 0 else None
+        stream_bytes = HIT_WRITE_BYTES * st["rays"] + RAY_READ_BYTES * (st["rays"] - st["paths"])
+        ach_gbs = stream_bytes / kern_s / 1e9 if kern_s > 0 else None
         out = {
             "metric": "Mrays/s", "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -175,11 +187,14 @@ def main():
             "ms_per_frame": dt / args.steps * 1e3,
             "roofline": {"bound": "valu", "achieved": ach_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": (ach_tflops / PEAK_FP32_TFLOPS) if ach_tflops else None, "traffic": None,
-                         "kernel": "bounce_kernel", "launches": kern_launches,
+                         "kernel": "intersect_kernel", "launches": kern_launches,
                          "avg_launch_ms": (float(kt[0]) / kern_launches) if kern_launches else None,
                          "flop_per_ray": flop_per_ray, "rays_per_launch": rays_rank0 / kern_launches if kern_launches else None},
+            # the same kernel against HBM: ray records in, hit records out (the scene itself is read from LDS)
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                             "frac": (ach_gbs / PEAK_HBM_GBS) if ach_gbs else None, "byte_per_ray": byte_per_ray},
+                             "frac": (ach_gbs / PEAK_HBM_GBS) if ach_gbs else None, "traffic": None,
+                             "stream_byte_per_ray": stream_bytes / rays_rank0 if rays_rank0 else None,
+                             "scene_byte_per_ray_from_lds": scene_byte_per_ray},
             "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -136,6 +136,9 @@ int rt_engine_set_window(rt_engine* e, int x0, int y0, int x1, int y1);
 /* Scatter gathered tiles (n_ranks packed buffers back to back, as an all-gather / gather leaves them) into a frame. */
 int rt_engine_assemble(rt_engine* e, const uint8_t* d_gathered, int n_ranks, uint8_t* d_rgba, void* stream);
 int rt_engine_sync(rt_engine* e);                                      /* waits for the engine's stream */
+/* 1 when everything queued on the engine's stream has finished, 0 while work is still running — what the front end's
+ * FrameManager::NeedUpdatingTexture (FrameManager.cpp:40-48) learns from its per-thread flags.  Never blocks. */
+int rt_engine_poll(rt_engine* e);
 /* FrameManager::GetTexturePixelsToPresent (FrameManager.cpp:60-71): waits, then copies the engine's own frame buffer. */
 int rt_engine_read_frame(rt_engine* e, uint8_t* rgba_out);
 /* Per-sample outputs (parity/debug).  rt_engine_keep_samples(e, 1) makes following renders record them; they can be read

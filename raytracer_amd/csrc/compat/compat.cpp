@@ -1,0 +1,113 @@
+// World and FrameManager of the adapter (see World.h / FrameManager.h in this directory).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "FrameManager.h"
+
+namespace {
+void check(int rc, const char* what) {
+    // the reference breaks into the debugger on asset errors (DataUtility.cpp:24-27) and rethrows thread-spawn errors
+    // (FrameManager.cpp:16-25); the adapter reports and throws
+    if (rc < 0) {
+        std::cout << what << ": " << rt_last_error() << std::endl;
+        throw std::runtime_error(std::string(what) + ": " + rt_last_error());
+    }
+}
+}  // namespace
+
+World::World(float time) : camera({glm::vec3{0, 3, -10}, glm::vec3{0, 0, 1}}) {   // World.cpp:48
+    rt_config cfg;
+    rt_config_defaults(&cfg);
+    cfg.width = WINDOW_WIDTH; cfg.height = WINDOW_HEIGHT;
+    cfg.samples_per_axis = SAMPLES_PER_PIXEL_AXIS; cfg.bounces = LIGHT_BOUNCE_AMOUNT;
+    cfg.fov = FIELD_OF_VIEW; cfg.skybox_brightness = SKYBOX_BRIGHTNESS;
+    cfg.dof_intensity = DEPTH_OF_FIELD_INTENSITY; cfg.focus_distance = FOCUS_DISTANCE;
+    if (const char* d = getenv("RT_DEVICE")) cfg.device = atoi(d);
+    check(rt_engine_create(&cfg, &engine), "rt_engine_create");
+    BuildScene(time);
+}
+World::~World() {
+    rt_engine_destroy(engine);
+    rt_scene_destroy(scene);
+}
+void World::BuildScene(float time) {
+    rt_scene* fresh = nullptr;
+    check(rt_scene_create(&fresh), "rt_scene_create");
+    const char* root = getenv("RT_ASSET_DIR");
+    int rc = rt_scene_add_default_objects(fresh, root ? root : ".", time);
+    if (rc >= 0) rc = rt_scene_build(fresh, buildKey);
+    if (rc < 0) { rt_scene_destroy(fresh); check(rc, "scene"); }
+    check(rt_engine_set_scene(engine, fresh), "rt_engine_set_scene");
+    rt_scene_destroy(scene);
+    scene = fresh;
+}
+// The reference deletes and rebuilds the whole scene, reloading the OBJ and PNG files, for every frame (World.cpp:59-66).
+// The compiled-in scene does not depend on `time` (only the "#else" scene of World.cpp:34-40 does), so the adapter keeps
+// the scene it has: same pixels, no per-frame rebuild.
+void World::CreateWithNewTime(float) {}
+void World::SyncCamera() {
+    float cam[12];
+    camera.Pack(cam);
+    check(rt_engine_set_camera(engine, cam), "rt_engine_set_camera");
+}
+glm::u8vec3 World::CalculateColorForScreenPosition(int x, int y) {
+    SyncCamera();
+    check(rt_engine_set_window(engine, x, y, x + 1, y + 1), "rt_engine_set_window");
+    check(rt_engine_render(engine, frameSeed, 0, 1, nullptr, nullptr), "rt_engine_render");
+    static thread_local std::vector<uint8_t> frame;
+    frame.resize((size_t)WINDOW_WIDTH * WINDOW_HEIGHT * 4);
+    check(rt_engine_read_frame(engine, frame.data()), "rt_engine_read_frame");
+    check(rt_engine_set_window(engine, 0, 0, WINDOW_WIDTH, WINDOW_HEIGHT), "rt_engine_set_window");
+    const uint8_t* p = &frame[((size_t)y * WINDOW_WIDTH + x) * 4];
+    return glm::u8vec3(p[3], p[2], p[1]);   // stored [A,B,G,R] (FrameManager.cpp:91-94)
+}
+glm::vec3 World::GetRayColor(const Ray& ray, int bounceAmount) {
+    const float o[3] = {ray.pos.x, ray.pos.y, ray.pos.z}, d[3] = {ray.direction.x, ray.direction.y, ray.direction.z};
+    const uint32_t key = frameSeed;
+    float rgb[3];
+    check(rt_engine_ray_color(engine, 1, o, d, bounceAmount, &key, rgb), "rt_engine_ray_color");
+    return {rgb[0], rgb[1], rgb[2]};
+}
+
+void FrameManager::StartNewFrame() {
+    TerminateAllThreads();
+    time += 1.0f;
+    world.CreateWithNewTime(time);
+    memset(texturePixels.data(), 0, texturePixels.size());   // FrameManager.cpp:13
+    world.SyncCamera();
+    world.frameSeed++;
+    check(rt_engine_render(world.Engine(), world.frameSeed, 0, 1, nullptr, nullptr), "rt_engine_render");
+    state = State::Rendering;
+    pixelsCurrent = false;
+#if LOG_BENCHMARK
+    frameStartTime = std::chrono::system_clock::now();
+#endif
+}
+void FrameManager::TerminateAllThreads() {
+    check(rt_engine_sync(world.Engine()), "rt_engine_sync");
+}
+bool FrameManager::NeedUpdatingTexture() {
+    if (state == State::AllComplete || state == State::Idle) return false;
+    if (rt_engine_poll(world.Engine()) == 1) FinishFrame();
+    return true;
+}
+void FrameManager::FinishFrame() {
+    state = State::AllComplete;
+#if LOG_BENCHMARK
+    std::chrono::duration<double> dur = std::chrono::system_clock::now() - frameStartTime;
+    std::cout << "Frame calculating time: " << dur.count() << std::endl;
+#endif
+}
+void* FrameManager::GetTexturePixelsToPresent() {
+    if (!pixelsCurrent && state != State::Idle) {
+        check(rt_engine_read_frame(world.Engine(), texturePixels.data()), "rt_engine_read_frame");   // waits for the frame
+        pixelsCurrent = true;
+    }
+    return texturePixels.data();
+}
+void FrameManager::ContinueWorkingOnImage() {}

@@ -18,6 +18,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -31,9 +32,13 @@ using namespace rtd;
 namespace {
 
 constexpr int IBLOCK = 512;         // intersect: 8 waves per block; two blocks per CU, each with its own copy of the scene in LDS
-constexpr int REFILL_AT = 16;       // a wave fetches new rays once this many lanes are idle
-constexpr int CHUNK = 256;          // queue positions a wave reserves per atomic
-constexpr int INNER_QUORUM = 24;    // lanes on inner nodes needed to repeat the box-test phase
+constexpr int STILE = 1024;         // shade: queue positions a block handles per round (survivors staged in 32 KiB of LDS)
+// intersect scheduling knobs (defaults in rt_engine_create; RT_REFILL_AT / RT_QUORUM / RT_CHUNK override them for tuning)
+struct Tune {
+    int refill_at;   // a wave fetches new rays once this many lanes are idle
+    int quorum;      // lanes on inner entries needed to repeat the box-test phase
+    int chunk;       // queue positions a wave reserves per atomic (shrunk when a pass holds few rays)
+};
 
 struct Cam { V3 pos, fwd, u, v; };
 struct Cfg { int W, H, S, B; float fov, sky, dof, focus; };
@@ -118,7 +123,7 @@ __device__ __forceinline__ bool fetch_ray(const Cam& cam, const Cfg& g, const Ba
 
 // ---- intersect (World.cpp:105-119) ----------------------------------------------------------------------------------
 template <bool FIRST, bool STAGED>
-__global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cfg g, Batch bt, Queues q, int pass, Debug dbg) {
+__global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cfg g, Batch bt, Queues q, int pass, Debug dbg, Tune tune) {
     extern __shared__ float4 smem[];
     Store st;
     if (STAGED) {   // whole scene (entries + triangles) into LDS once per block; blocks are persistent
@@ -138,16 +143,20 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
     uint32_t my_idx = 0;
     // the wave owns queue positions [mine, mine_end); it reserves CHUNK more with one atomic when they run out
     uint32_t mine = 0, mine_end = 0;
+    // few rays in the pass: smaller reservations, so that every wave of the grid gets some
+    const uint32_t waves = gridDim.x * (IBLOCK / 64);
+    uint32_t chunk = (n_in / (waves * 2u)) & ~63u;
+    chunk = chunk < 64u ? 64u : (chunk > (uint32_t)tune.chunk ? (uint32_t)tune.chunk : chunk);
     bool drained = false;   // wave-uniform: every queue position has been handed out
     for (;;) {
         const unsigned long long idle = __ballot(!w.busy);
-        if (!drained && __popcll(idle) >= REFILL_AT) {
+        if (!drained && __popcll(idle) >= tune.refill_at) {
             if (mine == mine_end) {
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(cursor, (uint32_t)CHUNK);
+                if (lane == 0) base = atomicAdd(cursor, chunk);
                 base = (uint32_t)__shfl((int)base, 0);
                 mine = base < n_in ? base : n_in;
-                mine_end = base + CHUNK < n_in ? base + CHUNK : n_in;
+                mine_end = base + chunk < n_in ? base + chunk : n_in;
             }
             if (mine == mine_end) drained = true;
             else {
@@ -167,7 +176,7 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
             if (drained) break;
             continue;
         }
-        if (walk_round(sc, st, w, INNER_QUORUM)) {
+        if (walk_round(sc, st, w, tune.quorum)) {
             q.hit[my_idx] = make_float4(w.c.dist, __int_as_float(w.c.best), w.c.u, w.c.v);
             q.hit_inst[my_idx] = w.c.inst;
         }
@@ -177,10 +186,19 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
 // ---- shade + compact (World.cpp:121-170) ------------------------------------------------------------------------------
 template <bool FIRST>
 __global__ __launch_bounds__(256) void shade_kernel(Scene sc, Cam cam, Cfg g, Batch bt, Queues q, int pass, Debug dbg) {
+    // A block shades STILE consecutive queue positions per round and collects the surviving rays in LDS; one global
+    // atomic per round then reserves their places in the outgoing queue (a per-wave atomic on the one counter would
+    // serialise millions of requests on a single L2 line), and the copy-out is fully coalesced.
+    __shared__ float4 s_a[STILE], s_b[STILE];
+    __shared__ uint32_t s_count, s_base;
     const int qin = (pass + 1) & 1, qout = pass & 1;
     const uint32_t n_in = FIRST ? (uint32_t)bt.n_pixels * (uint32_t)(g.S * g.S) : q.counts[pass];
-    const uint32_t n_round = (n_in + 63u) & ~63u;   // whole waves stay together for the ballot below
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n_round; i += gridDim.x * blockDim.x) {
+    const uint32_t n_tiles = (n_in + STILE - 1) / STILE;
+    for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+      if (threadIdx.x == 0) s_count = 0;
+      __syncthreads();
+      for (uint32_t k = 0; k < STILE / 256; k++) {
+        const uint32_t i = tile * STILE + k * 256 + threadIdx.x;
         Ray ray;
         Rng rng;
         uint32_t slot = 0, depth = 0;
@@ -229,20 +247,30 @@ __global__ __launch_bounds__(256) void shade_kernel(Scene sc, Cam cam, Cfg g, Ba
                 if (dbg.rng_draws) dbg.rng_draws[slot] = rng.ctr;
             }
         }
-        // compact: survivors of this wave take consecutive places in the outgoing queue
+        // compact: survivors of this wave (ballot + prefix count) take consecutive places in the block's staging tile
         const unsigned long long mask = __ballot(alive);
         if (mask) {
             const int lane = (int)(threadIdx.x & 63u);
             const int leader = __ffsll((long long)mask) - 1;
             uint32_t base = 0;
-            if (lane == leader) base = atomicAdd(&q.counts[pass + 1], (uint32_t)__popcll(mask));
+            if (lane == leader) base = atomicAdd(&s_count, (uint32_t)__popcll(mask));
             base = (uint32_t)__shfl((int)base, leader);
             if (alive) {
                 const uint32_t at = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-                q.a[qout][at] = make_float4(next.o.x, next.o.y, next.o.z, next.d.x);
-                q.b[qout][at] = make_float4(next.d.y, next.d.z, __uint_as_float(slot), __uint_as_float(rng.ctr | ((depth + 1u) << 24)));
+                s_a[at] = make_float4(next.o.x, next.o.y, next.o.z, next.d.x);
+                s_b[at] = make_float4(next.d.y, next.d.z, __uint_as_float(slot), __uint_as_float(rng.ctr | ((depth + 1u) << 24)));
             }
         }
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) s_base = s_count ? atomicAdd(&q.counts[pass + 1], s_count) : 0u;
+      __syncthreads();
+      const uint32_t n_out = s_count, out0 = s_base;
+      for (uint32_t j = threadIdx.x; j < n_out; j += 256) {
+          q.a[qout][out0 + j] = s_a[j];
+          q.b[qout][out0 + j] = s_b[j];
+      }
+      __syncthreads();
     }
 }
 
@@ -386,6 +414,7 @@ struct rt_engine {
     Debug dbg{nullptr, nullptr, nullptr, nullptr};
     bool debug_valid = false;
     int n_cus = 0;
+    Tune tune{16, 24, 256};
     int win[4] = {0, 0, 0, 0};          // x0, y0, width, height of the render window
     // statistics of the last render
     std::vector<uint32_t> h_counts;     // per batch: counts (B + 2), cursors (B + 2)
@@ -433,9 +462,9 @@ template <bool FIRST>
 void launch_intersect(rt_engine* e, hipStream_t st, const Cfg& g, const Batch& bt, const Queues& q, int pass) {
     const int blocks = e->n_cus * 2;
     if (e->staged_bytes)
-        hipLaunchKernelGGL((intersect_kernel<FIRST, true>), dim3(blocks), dim3(IBLOCK), e->staged_bytes, st, e->sc, e->cam, g, bt, q, pass, e->dbg);
+        hipLaunchKernelGGL((intersect_kernel<FIRST, true>), dim3(blocks), dim3(IBLOCK), e->staged_bytes, st, e->sc, e->cam, g, bt, q, pass, e->dbg, e->tune);
     else
-        hipLaunchKernelGGL((intersect_kernel<FIRST, false>), dim3(blocks), dim3(IBLOCK), 0, st, e->sc, e->cam, g, bt, q, pass, e->dbg);
+        hipLaunchKernelGGL((intersect_kernel<FIRST, false>), dim3(blocks), dim3(IBLOCK), 0, st, e->sc, e->cam, g, bt, q, pass, e->dbg, e->tune);
 }
 
 // the passes of one batch: pass 0 generates its rays, passes 1..B read the queue the previous pass filled.  counts points
@@ -510,6 +539,9 @@ int rt_engine_create(const rt_config* cfg, rt_engine** out) {
     HIP_TRY(hipMalloc((void**)&e->d_frame, (size_t)cfg->width * cfg->height * 4));
     HIP_TRY(hipMemset(e->d_frame, 0, (size_t)cfg->width * cfg->height * 4));
     e->n_counts = cfg->bounces + 2;
+    if (const char* v = getenv("RT_REFILL_AT")) e->tune.refill_at = std::max(1, std::min(64, atoi(v)));
+    if (const char* v = getenv("RT_QUORUM")) e->tune.quorum = std::max(1, std::min(65, atoi(v)));
+    if (const char* v = getenv("RT_CHUNK")) e->tune.chunk = std::max(64, atoi(v) & ~63);
     *out = e;
     return RT_OK;
 }
@@ -663,6 +695,15 @@ int rt_engine_sync(rt_engine* e) {
     HIP_TRY(hipSetDevice(e->cfg.device));
     HIP_TRY(hipStreamSynchronize(e->stream));
     return RT_OK;
+}
+
+int rt_engine_poll(rt_engine* e) {
+    if (!e) return fail(RT_E_INVALID, "null engine");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const hipError_t rc = hipStreamQuery(e->stream);
+    if (rc == hipErrorNotReady) return 0;
+    HIP_TRY(rc);
+    return 1;
 }
 
 int rt_engine_read_frame(rt_engine* e, uint8_t* rgba_out) {

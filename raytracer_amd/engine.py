@@ -81,6 +81,7 @@ SIGNATURES = {
     "rt_engine_set_window": (C.c_int, [_V, C.c_int, C.c_int, C.c_int, C.c_int]),
     "rt_engine_assemble": (C.c_int, [_V, _V, C.c_int, _V, _V]),
     "rt_engine_sync": (C.c_int, [_V]),
+    "rt_engine_poll": (C.c_int, [_V]),
     "rt_engine_read_frame": (C.c_int, [_V, u8p]),
     "rt_engine_keep_samples": (C.c_int, [_V, C.c_int]),
     "rt_engine_read_samples": (C.c_int, [_V, _V, _V, _V, _V]),
@@ -334,6 +335,10 @@ class Engine:
 
     def sync(self):
         _check(self.L.rt_engine_sync(self.h))
+
+    def poll(self):
+        """True when everything queued on the engine's stream has finished (never blocks)."""
+        return bool(_check(self.L.rt_engine_poll(self.h)))
 
     def read_frame(self):
         out = np.zeros((self.cfg.height, self.cfg.width, 4), np.uint8)

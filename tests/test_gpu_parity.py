@@ -340,3 +340,29 @@ def test_error_behaviour(rt, gpu_default):
     with pytest.raises(rt.RtError):
         e.read_samples()                 # not armed
     assert E.lib().rt_last_error()
+
+
+def test_front_end_adapter_matches_the_c_abi(rt, gpu_default, tmp_path):
+    """raytracer_amd/compat_demo drives the FrameManager / World / Camera adapter (raytracer_amd/csrc/compat, the
+    reference's class interface over the C ABI) like the reference's main loop, at the resolution and quality of the
+    front end's Constants.h it was compiled against; its frame must be the frame the C ABI renders for the same
+    scene key, frame seed and camera."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    demo = os.path.join(ROOT, "raytracer_amd", "compat_demo")
+    assert os.path.exists(demo), "raytracer_amd/compat_demo is not built (make -C raytracer_amd/csrc compat)"
+    out = tmp_path / "frame.raw"
+    env = dict(os.environ, RT_ASSET_DIR=os.path.join(ROOT, "assets"))
+    log = subprocess.run([demo, "1", str(out)], env=env, capture_output=True, text=True, timeout=110)
+    assert log.returncode == 0, log.stdout + log.stderr
+    assert "Frame calculating time" in log.stdout          # LOG_BENCHMARK print of FrameManager::FinishFrame
+    raw = np.fromfile(out, np.uint8)
+    cfg = rt.default_config()                              # the values of Constants.h
+    W, H = cfg.width, cfg.height
+    assert raw.size == W * H * 4
+    e = rt.Engine(cfg)
+    e.set_scene(rt.default_scene(1))                       # World::buildKey of the adapter
+    e.set_camera(rt.camera_look(CAM_POS, CAM_LOOK))
+    assert_bits(raw.reshape(H, W, 4), e.render_frame(2), "adapter frame vs C ABI frame")   # first frame: frameSeed 2
+    assert e.poll() is True

@@ -141,3 +141,18 @@ def test_engine_refuses_to_run_without_a_gpu(rt):
         pytest.skip("a GPU is present")
     with pytest.raises(rt.RtError):
         rt.Engine(rt.default_config(width=16, height=16))
+
+
+def test_front_end_adapter_compiles_against_the_front_end_headers(tmp_path):
+    """The FrameManager / World / Camera adapter must compile with the front end's own Constants.h and GLM (both stay in
+    the front end's tree, so this runs only where that tree is present)."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    front, glm = "/root/reference/Raytracer/src", "/root/reference/glm/glm"
+    if not (os.path.exists(front + "/Constants.h") and os.path.exists(glm + "/glm.hpp")):
+        pytest.skip("front-end sources are not on this machine")
+    comp = os.path.join(ROOT, "raytracer_amd", "csrc", "compat")
+    for src in ("compat.cpp", "headless_main.cpp"):
+        subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I" + comp, "-I" + front, "-I" + glm,
+                               os.path.join(comp, src)])
