@@ -88,10 +88,19 @@ def cpu_baseline(workload, W, H, S, B, threads):
         px += x1 * (min(H, y0 + rows) - y0)
     dt = time.perf_counter() - t0
     c = s.counters()
+    # the reference's own thread count (THREAD_COUNT 7, Constants.h:6) on 16 strips of 8 rows (c3: one segment)
+    t0 = time.perf_counter()
+    for k in range(16 if workload != "c3" else 1):
+        y0 = int((k + 0.5) * H / 16)
+        s.render(cam, W, H, S, B, SEED, rect=(0, y0, W if workload != "c3" else W // 16, min(H, y0 + (8 if workload != "c3" else 1))),
+                 threads=7, want=("rgba",))
+    dt7 = time.perf_counter() - t0
+    rays7 = s.counters()["rays"] - c["rays"]
     flops = sum(FLOP_INTERSECT[k] * c[k] for k in FLOP_INTERSECT)
     flops_shade = sum(FLOP_SHADE[k] * c[k] for k in FLOP_SHADE)
     nbytes = sum(SCENE_BYTE_WEIGHTS[k] * c[k] for k in SCENE_BYTE_WEIGHTS)
     return {"value": c["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "value_7_threads": rays7 / dt7 / 1e6,
             "sample": f"{n_strips} strips x {rows} rows = {px} pixels of the {W}x{H} frame, all {S * S} spp and {B} bounces, "
                       f"{c['rays']} rays in {dt:.1f} s; contiguous pixel ranges per thread as FrameManager.cpp:80-82",
             "intersect_flop_per_ray": flops / c["rays"], "shade_flop_per_ray": flops_shade / c["rays"],
@@ -187,6 +196,8 @@ def main():
             "ms_per_frame": dt / args.steps * 1e3,
             "roofline": {"bound": "valu", "achieved": ach_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": (ach_tflops / PEAK_FP32_TFLOPS) if ach_tflops else None, "traffic": None,
+                         # the reference's unfused, unpacked arithmetic (kept for bit-exact ids) can issue 1/4 of the peak
+                         "frac_of_unfused_peak": (ach_tflops / (PEAK_FP32_TFLOPS / 4)) if ach_tflops else None,
                          "kernel": "intersect_kernel", "launches": kern_launches,
                          "avg_launch_ms": (float(kt[0]) / kern_launches) if kern_launches else None,
                          "flop_per_ray": flop_per_ray, "rays_per_launch": rays_rank0 / kern_launches if kern_launches else None},
