@@ -129,7 +129,7 @@ struct Scene {
     const rt::ImageRec* images; const uint8_t* texels;
     uint32_t sky_off, sky_w, sky_h;
     int top_end, stale_entry, n_planes;
-    int n_entries, n_tris, fast_div_ok;
+    int n_entries, n_tris, fast_div_ok, idle_entry;
 };
 struct Ray { V3 o, d; };
 
@@ -289,9 +289,10 @@ __device__ __forceinline__ void from_instance(const float4 i0, const float4 i1, 
 // A slab test divides six differences by the three direction components of the SAME ray.  With y = RN(1/b) computed once
 // per ray by a true division, RN(a/b) is recovered from y by two residual corrections (Markstein's scheme: q ~ a*y,
 // r = a - b*q exactly by FMA, q += r*y), five ordinary instructions instead of the ~11 of the hardware's IEEE sequence.
-// The scheme is exact (a zero quotient possibly with the other sign, which no comparison can tell) while nothing over/underflows; `usable` below admits a ray
-// only if that holds for every box of the scene: |dir| components in [2^-20, 2^20], origin components 0 or in
-// [2^-50, 2^40] — the host checks the same of all box coordinates (Scene::fast_div_ok).  Other rays take true division.
+// The scheme is exact (a zero quotient possibly with the other sign, which no comparison can tell) while nothing
+// over/underflows; `usable` below admits a ray only if that holds for every box of the scene: |dir| components in
+// [2^-20, 2^20], origin components 0 or in [2^-50, 2^40] — the host checks the same of all box coordinates
+// (Scene::fast_div_ok).  Other rays take true division.
 __device__ __forceinline__ float div_by(float a, float b, float y) {
     float q = a * y;
     float r = __builtin_fmaf(-b, q, a);
@@ -301,32 +302,9 @@ __device__ __forceinline__ float div_by(float a, float b, float y) {
 }
 __device__ __forceinline__ bool mag_in(float v, float lo, float hi) { const float a = fabsf(v); return a >= lo && a <= hi; }
 __device__ __forceinline__ bool coord_ok(float v) { return v == 0.0f || mag_in(v, 8.8817841970012523e-16f, 1.099511627776e12f); }
-struct Recip { float x, y, z; bool usable; };
-__device__ __forceinline__ Recip make_recip(const Ray& r, bool scene_ok) {
-    Recip k;
-    k.usable = scene_ok && mag_in(r.d.x, 9.5367431640625e-07f, 1048576.0f) && mag_in(r.d.y, 9.5367431640625e-07f, 1048576.0f) &&
-               mag_in(r.d.z, 9.5367431640625e-07f, 1048576.0f) && coord_ok(r.o.x) && coord_ok(r.o.y) && coord_ok(r.o.z);
-    k.x = 1.0f / r.d.x; k.y = 1.0f / r.d.y; k.z = 1.0f / r.d.z;
-    return k;
-}
-// BoundingBox::DoesRayHit with the divisions done through the ray's reciprocals: same quotients, same decisions
-// Straight-line form: all six quotients, then the three rejection tests combined — no early exit, so the wave runs one
-// instruction stream with no exec-mask bookkeeping.  Rays admitted to this path produce finite quotients only, for
-// which max/min by comparison (glm) and the hardware max/min agree.
-__device__ __forceinline__ bool box_hit_recip(V3 mn, V3 mx, const Ray& r, const Recip& k) {
-    const bool px = r.d.x >= 0, py = r.d.y >= 0, pz = r.d.z >= 0;
-    const float txmin = div_by((px ? mn.x : mx.x) - r.o.x, r.d.x, k.x);
-    const float txmax = div_by((px ? mx.x : mn.x) - r.o.x, r.d.x, k.x);
-    const float tymin = div_by((py ? mn.y : mx.y) - r.o.y, r.d.y, k.y);
-    const float tymax = div_by((py ? mx.y : mn.y) - r.o.y, r.d.y, k.y);
-    const float tzmin = div_by((pz ? mn.z : mx.z) - r.o.z, r.d.z, k.z);
-    const float tzmax = div_by((pz ? mx.z : mn.z) - r.o.z, r.d.z, k.z);
-    const bool rej_xy = (txmin > tymax) | (tymin > txmax);
-    const float t1 = fmaxf(txmin, tymin), t2 = fminf(txmax, tymax);
-    const bool rej_z = (t1 > tzmax) | (tzmin > t2);
-    const float tmin = fmaxf(t1, tzmin), tmax = fminf(t2, tzmax);
-    const bool behind = (tmin < 0.0f) & (tmax < 0.0f);
-    return !(rej_xy | rej_z | behind);
+__device__ __forceinline__ bool ray_usable(const Ray& r) {
+    return mag_in(r.d.x, 9.5367431640625e-07f, 1048576.0f) && mag_in(r.d.y, 9.5367431640625e-07f, 1048576.0f) &&
+           mag_in(r.d.z, 9.5367431640625e-07f, 1048576.0f) && coord_ok(r.o.x) && coord_ok(r.o.y) && coord_ok(r.o.z);
 }
 
 // ---------------------------------------------------------------------------------------------------- closest hit
@@ -336,115 +314,268 @@ __device__ __forceinline__ bool box_hit_recip(V3 mn, V3 mx, const Ray& r, const 
 //   leaf assigned before rejecting (Object.cpp:17-19, 534-550), which the plane is then compared against.
 struct Closest { float dist; int best; int inst; float u, v; bool hit; };
 
-// Per-lane traversal state.  The lane holds the entry it stands on (lo, hi, kind) so that the wave can decide which
-// phase to run: lanes on inner nodes step together (box tests), lanes on leaves test primitives together.
-enum : int { K_END = -1 };
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int sk_kind(uint32_t sk) { return (int)(sk >> rt::SK_SHIFT); }
+__device__ __forceinline__ int sk_payload(uint32_t sk) { return (int)(sk & rt::SK_MASK); }
+
+// Per-lane traversal state.  The lane holds the entry it stands on so that the wave can decide which phase to run: lanes
+// on inner entries step together (box tests), lanes on leaves test primitives together.  A lane without a ray stands on
+// the scene's IDLE entry.
 struct Walker {
-    Ray top, cur;            // the ray as given, and in the current (instance) frame
-    Recip rc;
-    int i, end, resume, inst, stale, alpha_img, kind;
-    float4 lo, hi;
+    Ray top;                 // the ray as given
+    // the ray in the current (instance) frame, kept as the operand pairs of the box step:
+    // (o.x, o.y) (o.z, 1/d.x) (1/d.y, 1/d.z) (d.x, d.y) (d.z, -)
+    f2 p0, p1, p2, p3, p4;
+    bool usable;             // the reciprocal path reproduces true division for this ray
+    int i, resume, inst, stale, alpha_img;
+    f2 e01, e23, e45;        // dwords 0..5 of the entry
+    uint32_t sk;             // dword 6: kind << 28 | payload; for an inner entry (kind 0) simply the skip index
     Closest c;
-    bool busy;
 };
 // entries (and, when staged, triangles) either in LDS or in global memory
-struct Store { const float4* ent; const float4* tris; };   // ent: lo/hi interleaved, 2 x float4 per entry
+struct Store { const float4* ent; const float4* tris; };   // 2 x float4 per entry
 
+__device__ __forceinline__ Ray walker_ray(const Walker& w) {
+    Ray r;
+    r.o = mk(w.p0.x, w.p0.y, w.p1.x); r.d = mk(w.p3.x, w.p3.y, w.p4.x);
+    return r;
+}
+__device__ __forceinline__ void walker_set_ray(Walker& w, const Ray& r, bool scene_ok) {
+    w.usable = scene_ok && ray_usable(r);
+    w.p0 = f2{r.o.x, r.o.y}; w.p1 = f2{r.o.z, 1.0f / r.d.x}; w.p2 = f2{1.0f / r.d.y, 1.0f / r.d.z};
+    w.p3 = f2{r.d.x, r.d.y}; w.p4 = f2{r.d.z, 0.0f};
+}
 __device__ __forceinline__ void walker_load(const Store& st, Walker& w) {
-    if (w.i < w.end) {
-        w.lo = st.ent[2 * w.i];
-        w.hi = st.ent[2 * w.i + 1];
-        w.kind = __float_as_int(w.hi.w);
-    } else w.kind = K_END;
+    const f2* e = reinterpret_cast<const f2*>(st.ent) + 4 * w.i;
+    w.e01 = e[0]; w.e23 = e[1]; w.e45 = e[2];
+    w.sk = reinterpret_cast<const uint32_t*>(e)[6];
+}
+__device__ __forceinline__ void walker_idle(const Scene& sc, Walker& w) {
+    w.i = sc.idle_entry; w.sk = (uint32_t)rt::ENT_IDLE << rt::SK_SHIFT;
+    w.e01 = f2{0, 0}; w.e23 = f2{0, 0}; w.e45 = f2{0, 0};
+    w.top.o = mk(0, 0, 0); w.top.d = mk(0, 0, 1);
+    w.p0 = f2{0, 0}; w.p1 = f2{0, 1}; w.p2 = f2{1, 1}; w.p3 = f2{1, 1}; w.p4 = f2{1, 0}; w.usable = true;
+    w.resume = 0; w.inst = -1; w.stale = -1; w.alpha_img = -1;
+    w.c.dist = FLT_MAX; w.c.best = -1; w.c.inst = -1; w.c.u = 0; w.c.v = 0; w.c.hit = false;
 }
 __device__ __forceinline__ void walker_start(const Scene& sc, const Store& st, Walker& w, const Ray& ray) {
-    w.top = ray; w.cur = ray;
-    w.rc = make_recip(ray, sc.fast_div_ok != 0);
-    w.i = 0; w.end = sc.top_end; w.resume = 0; w.inst = -1; w.stale = sc.stale_entry; w.alpha_img = -1;
+    w.top = ray;
+    walker_set_ray(w, ray, sc.fast_div_ok != 0);
+    w.i = 0; w.resume = 0; w.inst = -1; w.stale = sc.stale_entry; w.alpha_img = -1;
     w.c.dist = FLT_MAX; w.c.best = -1; w.c.inst = -1; w.c.u = 0; w.c.v = 0; w.c.hit = false;
-    w.busy = true;
     walker_load(st, w);
 }
-// BVH_Node::Intersect (Object.cpp:241-252) on an inner entry: into the left subtree, or past the whole subtree.
-// Called by the whole wave; `act` marks the lanes that stand on an inner entry.  The reciprocal path runs unmasked
-// (lanes that are not `act` compute on whatever they hold and discard it); lanes whose ray is not admitted to it are
-// rare and redo the test with true divisions under a wave-uniform branch.
-__device__ __forceinline__ void walker_inner(const Store& st, Walker& w, bool act) {
-    bool h = box_hit_recip(xyz(w.lo), xyz(w.hi), w.cur, w.rc);
-    const bool slow = act && !w.rc.usable;
-    if (__any(slow)) {
-        if (slow) h = box_hit(xyz(w.lo), xyz(w.hi), w.cur);
-    }
-    if (act) {
-        w.i = h ? w.i + 1 : __float_as_int(w.lo.w);
-        walker_load(st, w);
+
+// BVH_Node::Intersect (Object.cpp:241-252) on inner entries — BoundingBox::DoesRayHit (DataUtility.cpp:35-82), then into
+// the left subtree or past the whole subtree:  i = hit ? i + 1 : skip, fetch entry i  — repeated for the lanes of the
+// wave that stand on an inner entry (and whose ray is admitted to the reciprocal path) for as long as at least
+// `quorum` lanes do, plus one last step for the stragglers.
+//
+// This loop is the instruction stream the renderer spends most of its time in, so it is written out by hand: 33 vector
+// instructions per step where the compiler's schedule of the same arithmetic needs 50 to 70 (it keeps the entry in
+// four-register tuples, rebuilds operand pairs and copies loop-carried values around the loop).
+//   * the entry holds the bounds of an axis side by side (min.x, max.x) (min.y, max.y) (min.z, max.z): one packed
+//     subtract, multiply and four packed FMAs per axis give both quotients (div_by above, two lanes wide); per-ray
+//     constants are broadcast out of their pairs with op_sel, so they need no registers of their own;
+//   * the three axes are interleaved: a packed result is never consumed by the next instruction (which would need a
+//     wait state on gfx950);
+//   * only boxes with min <= max and rays admitted to the reciprocal path come here (finite quotients only).  The
+//     reference rejects when an axis's entry distance exceeds ANOTHER axis's exit distance (DataUtility.cpp:56,71); an
+//     axis's own entry never exceeds its own exit for such a box, so "not rejected" is max3(entries) <= min3(exits), and
+//     the last test, both distances negative (:78), is then "exit < 0".  Entry/exit per axis are picked by the sign of
+//     the direction (px, py, pz: lane masks of d >= 0), as the reference does;
+//   * the loads land in the registers that already hold the entry (tied operands): nothing is copied;
+//   * the lanes that take a step are enabled through exec inside the block (restored before every test and at the
+//     end), so the surrounding control flow is wave-uniform.
+// v2..v8 are used as scratch registers by name because the halves of a register pair cannot be named through operands.
+// Every lane of the wave must be enabled at the call.
+template <bool LDS>
+__device__ __forceinline__ void box_steps(const Store& st, Walker& w, int quorum) {
+    const unsigned long long px = __ballot(w.p3.x >= 0), py = __ballot(w.p3.y >= 0), pz = __ballot(w.p4.x >= 0);
+    const unsigned long long usable = __ballot(w.usable), saved = __ballot(true);
+    f2 t0, t1, t2, r0, r1, r2;
+    unsigned long long m, m2;
+    int cnt;
+    if (LDS) {
+        const uint32_t base = (uint32_t)(uintptr_t)st.ent;   // LDS addresses are 32-bit offsets
+        asm volatile(
+                 "1:\n\t"
+                 "v_cmp_gt_u32_e32 vcc, 0x10000000, %3\n\t"
+                 "s_and_b64 %11, vcc, %23\n\t"
+                 "s_cmp_eq_u64 %11, 0\n\t"
+                 "s_cbranch_scc1 2f\n\t"
+                 "s_and_b64 exec, %25, %11\n\t"
+                 "v_pk_add_f32 %5, %0, %14 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                 "v_pk_add_f32 %6, %1, %14 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                 "v_pk_add_f32 %7, %2, %15 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                 "v_pk_mul_f32 v[2:3], %5, %15 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                 "v_pk_mul_f32 v[4:5], %6, %16 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+                 "v_pk_mul_f32 v[6:7], %7, %16 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                 "v_pk_fma_f32 %8, %17, v[2:3], %5 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 %9, %17, v[4:5], %6 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 %10, %18, v[6:7], %7 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[2:3], %8, %15, v[2:3] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 v[4:5], %9, %16, v[4:5] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 v[6:7], %10, %16, v[6:7] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 %8, %17, v[2:3], %5 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 %9, %17, v[4:5], %6 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 %10, %18, v[6:7], %7 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[2:3], %8, %15, v[2:3] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 v[4:5], %9, %16, v[4:5] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 v[6:7], %10, %16, v[6:7] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_cndmask_b32_e64 v8, v3, v2, %19\n\t"
+                 "v_cndmask_b32_e64 v3, v2, v3, %19\n\t"
+                 "v_cndmask_b32_e64 v2, v5, v4, %20\n\t"
+                 "v_cndmask_b32_e64 v5, v4, v5, %20\n\t"
+                 "v_cndmask_b32_e64 v4, v7, v6, %21\n\t"
+                 "v_cndmask_b32_e64 v7, v6, v7, %21\n\t"
+                 "v_max3_f32 v8, v8, v2, v4\n\t"
+                 "v_min3_f32 v3, v3, v5, v7\n\t"
+                 "v_cmp_le_f32_e32 vcc, v8, v3\n\t"
+                 "v_cmp_nlt_f32_e64 %12, v3, 0\n\t"
+                 "v_add_u32_e32 v2, 1, %4\n\t"
+                 "s_and_b64 vcc, vcc, %12\n\t"
+                 "s_bcnt1_i32_b64 %13, %11\n\t"
+                 "v_cndmask_b32_e32 %4, %3, v2, vcc\n\t"
+                 "v_lshl_add_u32 v2, %4, 5, %22\n\t"
+                 "ds_read_b64 %0, v2\n\t"
+                 "ds_read_b64 %1, v2 offset:8\n\t"
+                 "ds_read_b64 %2, v2 offset:16\n\t"
+                 "ds_read_b32 %3, v2 offset:24\n\t"
+                 "s_waitcnt lgkmcnt(0)\n\t"
+                 "s_mov_b64 exec, %25\n\t"
+                 "s_cmp_ge_u32 %13, %24\n\t"
+                 "s_cbranch_scc1 1b\n\t"
+                 "2:\n\t"
+                 : "+v"(w.e01), "+v"(w.e23), "+v"(w.e45), "+v"(w.sk), "+v"(w.i),
+                   "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&s"(m), "=&s"(m2), "=&s"(cnt)
+                 : "v"(w.p0), "v"(w.p1), "v"(w.p2), "v"(w.p3), "v"(w.p4), "s"(px), "s"(py), "s"(pz), "s"(base), "s"(usable),
+                   "s"(quorum), "s"(saved)
+                 : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "vcc", "scc", "memory");
+    } else {
+        const float4* base = st.ent;
+        asm volatile(
+                 "1:\n\t"
+                 "v_cmp_gt_u32_e32 vcc, 0x10000000, %3\n\t"
+                 "s_and_b64 %11, vcc, %23\n\t"
+                 "s_cmp_eq_u64 %11, 0\n\t"
+                 "s_cbranch_scc1 2f\n\t"
+                 "s_and_b64 exec, %25, %11\n\t"
+                 "v_pk_add_f32 %5, %0, %14 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                 "v_pk_add_f32 %6, %1, %14 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                 "v_pk_add_f32 %7, %2, %15 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                 "v_pk_mul_f32 v[2:3], %5, %15 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                 "v_pk_mul_f32 v[4:5], %6, %16 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+                 "v_pk_mul_f32 v[6:7], %7, %16 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                 "v_pk_fma_f32 %8, %17, v[2:3], %5 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 %9, %17, v[4:5], %6 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 %10, %18, v[6:7], %7 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[2:3], %8, %15, v[2:3] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 v[4:5], %9, %16, v[4:5] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 v[6:7], %10, %16, v[6:7] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 %8, %17, v[2:3], %5 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 %9, %17, v[4:5], %6 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 %10, %18, v[6:7], %7 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[2:3], %8, %15, v[2:3] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 v[4:5], %9, %16, v[4:5] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 v[6:7], %10, %16, v[6:7] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_cndmask_b32_e64 v8, v3, v2, %19\n\t"
+                 "v_cndmask_b32_e64 v3, v2, v3, %19\n\t"
+                 "v_cndmask_b32_e64 v2, v5, v4, %20\n\t"
+                 "v_cndmask_b32_e64 v5, v4, v5, %20\n\t"
+                 "v_cndmask_b32_e64 v4, v7, v6, %21\n\t"
+                 "v_cndmask_b32_e64 v7, v6, v7, %21\n\t"
+                 "v_max3_f32 v8, v8, v2, v4\n\t"
+                 "v_min3_f32 v3, v3, v5, v7\n\t"
+                 "v_cmp_le_f32_e32 vcc, v8, v3\n\t"
+                 "v_cmp_nlt_f32_e64 %12, v3, 0\n\t"
+                 "v_add_u32_e32 v2, 1, %4\n\t"
+                 "s_and_b64 vcc, vcc, %12\n\t"
+                 "s_bcnt1_i32_b64 %13, %11\n\t"
+                 "v_cndmask_b32_e32 %4, %3, v2, vcc\n\t"
+                 "v_lshlrev_b32_e32 v2, 5, %4\n\t"
+                 "global_load_dwordx2 %0, v2, %22\n\t"
+                 "global_load_dwordx2 %1, v2, %22 offset:8\n\t"
+                 "global_load_dwordx2 %2, v2, %22 offset:16\n\t"
+                 "global_load_dword %3, v2, %22 offset:24\n\t"
+                 "s_waitcnt vmcnt(0)\n\t"
+                 "s_mov_b64 exec, %25\n\t"
+                 "s_cmp_ge_u32 %13, %24\n\t"
+                 "s_cbranch_scc1 1b\n\t"
+                 "2:\n\t"
+                 : "+v"(w.e01), "+v"(w.e23), "+v"(w.e45), "+v"(w.sk), "+v"(w.i),
+                   "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&s"(m), "=&s"(m2), "=&s"(cnt)
+                 : "v"(w.p0), "v"(w.p1), "v"(w.p2), "v"(w.p3), "v"(w.p4), "s"(px), "s"(py), "s"(pz), "s"(base), "s"(usable),
+                   "s"(quorum), "s"(saved)
+                 : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "vcc", "scc", "memory");
     }
 }
-// one leaf-level action.  Returns true when the ray has finished (closest hit known, plane list merged).
+
+// one leaf-level action.  Returns true when the ray has finished (closest hit known, plane list merged); the lane is
+// idle from then on.
 __device__ __forceinline__ bool walker_leaf(const Scene& sc, const Store& st, Walker& w) {
-    if (w.kind == K_END) {
+    bool done = false;
+    const int kind = sk_kind(w.sk);
+    const Ray cur = walker_ray(w);
+    if (kind == rt::ENT_END) {
         if (w.inst >= 0) {   // PolygonMesh and its wrappers return to the top level
-            w.i = w.resume; w.end = sc.top_end; w.inst = -1; w.stale = sc.stale_entry; w.cur = w.top;
-            w.rc = make_recip(w.top, sc.fast_div_ok != 0);
-            walker_load(st, w);
-            return false;
+            w.i = w.resume; w.inst = -1; w.stale = sc.stale_entry;
+            walker_set_ray(w, w.top, sc.fast_div_ok != 0);
+        } else {
+            for (int p = 0; p < sc.n_planes; p++) {   // YPlane::Intersect (Object.cpp:139-149), merged as World.cpp:110-118
+                const float t = -(w.top.o.y - sc.planes[p].x) / w.top.d.y;
+                if (t < 0.001f) continue;             // "t < 1e-3" against a double: the same floats pass
+                if (t < w.c.dist) { w.c.hit = true; w.c.dist = t; w.c.best = -(p + 2); w.c.inst = -1; }
+            }
+            w.i = sc.idle_entry;
+            done = true;
         }
-        for (int p = 0; p < sc.n_planes; p++) {   // YPlane::Intersect (Object.cpp:139-149), merged as World.cpp:110-118
-            const float t = -(w.top.o.y - sc.planes[p].x) / w.top.d.y;
-            if (t < 0.001f) continue;             // "t < 1e-3" against a double: the same floats pass
-            if (t < w.c.dist) { w.c.hit = true; w.c.dist = t; w.c.best = -(p + 2); w.c.inst = -1; }
-        }
-        w.busy = false;
-        return true;
-    }
-    if (w.kind == rt::ENT_INSTANCE) {
-        const int ii = __float_as_int(w.lo.x);
+    } else if (kind == rt::ENT_INSTANCE) {
+        const int ii = sk_payload(w.sk);
         const float4* I = sc.inst + (size_t)ii * rt::RT_INST_F4;
         const float4 i0 = I[0], i1 = I[1], i2 = I[2], i3 = I[3];
-        w.cur = to_instance(i0, i1, i2, w.top);
-        w.rc = make_recip(w.cur, sc.fast_div_ok != 0);
+        walker_set_ray(w, to_instance(i0, i1, i2, w.top), sc.fast_div_ok != 0);
         w.resume = w.i + 1;
         w.stale = (w.i == sc.stale_entry) ? __float_as_int(i3.y) : -1;
         w.inst = ii;
         const float4 ob = sc.objects[(size_t)__float_as_int(i3.x) * rt::RT_OBJ_F4];
         w.alpha_img = __float_as_int(ob.y) == 2 ? __float_as_int(ob.z) : -1;
         w.i = __float_as_int(i2.z);
-        w.end = __float_as_int(i2.w);
-        walker_load(st, w);
-        return false;
+    } else if (kind == rt::ENT_INNER || kind == rt::ENT_INNER_INV) {
+        // the reference's test as written, with true divisions: a box with min > max on some axis, or a ray that is
+        // not admitted to the reciprocal path
+        const int skip = kind == rt::ENT_INNER ? (int)w.sk : __float_as_int(reinterpret_cast<const float*>(st.ent)[8 * (size_t)w.i + 7]);
+        w.i = box_hit(mk(w.e01.x, w.e23.x, w.e45.x), mk(w.e01.y, w.e23.y, w.e45.y), cur) ? w.i + 1 : skip;
+    } else {
+        float t = 0, u = 0, v = 0;
+        bool ok, wrote = false;
+        if (kind == rt::ENT_SPHERE) ok = sphere_test(mk(w.e01.x, w.e01.y, w.e23.x), w.e23.y, cur, t, wrote);
+        else if (kind == rt::ENT_CUBE) { V3 n; ok = cube_test(mk(w.e01.x, w.e01.y, w.e23.x), mk(w.e23.y, w.e45.x, w.e45.y), cur, t, n); }
+        else ok = tri_test(sc, st.tris, sk_payload(w.sk), w.alpha_img, cur, t, u, v, wrote);
+        if (ok) {
+            if (!w.c.hit || t < w.c.dist) { w.c.hit = true; w.c.dist = t; w.c.best = w.i; w.c.inst = w.inst; w.c.u = u; w.c.v = v; }
+        } else if (wrote && w.i == w.stale) w.c.dist = t;
+        w.i++;
     }
-    float t = 0, u = 0, v = 0;
-    bool ok, wrote = false;
-    if (w.kind == rt::ENT_SPHERE) ok = sphere_test(xyz(w.lo), w.lo.w, w.cur, t, wrote);
-    else if (w.kind == rt::ENT_CUBE) { V3 n; ok = cube_test(xyz(w.lo), xyz(w.hi), w.cur, t, n); }
-    else ok = tri_test(sc, st.tris, __float_as_int(w.lo.x), w.alpha_img, w.cur, t, u, v, wrote);
-    if (ok) {
-        if (!w.c.hit || t < w.c.dist) { w.c.hit = true; w.c.dist = t; w.c.best = w.i; w.c.inst = w.inst; w.c.u = u; w.c.v = v; }
-    } else if (wrote && w.i == w.stale) w.c.dist = t;
-    w.i++;
     walker_load(st, w);
-    return false;
-}
-// Run the lanes of a wave that are busy until all of them have finished.  Inner-node steps repeat while at least
-// `inner_quorum` lanes stand on inner nodes, so the (expensive) leaf code runs with many lanes enabled.
-// One round for a wave: box tests while at least `quorum` lanes stand on inner entries, then one step for everybody
-// (inner entries for the stragglers, a leaf-level action for the others).  `done` reports lanes whose ray finished.
-__device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Walker& w, int quorum) {
-    for (;;) {
-        const bool act = w.busy && w.kind == rt::ENT_INNER;
-        if (__popcll(__ballot(act)) < quorum) break;
-        walker_inner(st, w, act);
-    }
-    const bool act = w.busy && w.kind == rt::ENT_INNER;
-    if (__any(act)) walker_inner(st, w, act);
-    bool done = false;
-    if (w.busy && !act) done = walker_leaf(sc, st, w);
     return done;
 }
-// Run the busy lanes of a wave until all of them have finished.
-__device__ __forceinline__ void walk_wave_to_end(const Scene& sc, const Store& st, Walker& w) {
-    while (__any(w.busy)) walk_round(sc, st, w, 24);
+// One round for a wave: box steps while at least `quorum` lanes stand on inner entries (and once more for the
+// stragglers), then a leaf-level action for every lane that stands on something else.  Returns true in lanes whose ray
+// finished.
+template <bool LDS>
+__device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Walker& w, int quorum) {
+    box_steps<LDS>(st, w, quorum);
+    bool done = false;
+    const bool inner = w.sk < (1u << rt::SK_SHIFT) && w.usable;
+    if (!inner && sk_kind(w.sk) != rt::ENT_IDLE) done = walker_leaf(sc, st, w);
+    return done;
 }
+// Run the lanes of a wave until all of them have finished.
+__device__ __forceinline__ void walk_wave_to_end(const Scene& sc, const Store& st, Walker& w) {
+    while (__any(sk_kind(w.sk) != rt::ENT_IDLE)) walk_round<false>(sc, st, w, 24);
+}
+__device__ __forceinline__ bool walker_is_idle(const Walker& w) { return sk_kind(w.sk) == rt::ENT_IDLE; }
 
 struct Hit { V3 point, normal; float u, v; int object; };
 
@@ -458,20 +589,21 @@ __device__ inline void finalize_hit(const Scene& sc, const Ray& ray, const Close
         h.object = __float_as_int(pl.y);
         return;
     }
-    const float4 lo = sc.ent[2 * c.best], hi = sc.ent[2 * c.best + 1];
-    const int kind = __float_as_int(hi.w);
+    const float4 ea = sc.ent[2 * c.best], eb = sc.ent[2 * c.best + 1];
+    const uint32_t sk = __float_as_uint(eb.z);
+    const int kind = sk_kind(sk);
     if (kind == rt::ENT_SPHERE) {
         h.point = ray.o + ray.d * c.dist;
-        h.normal = normalize(h.point - xyz(lo));
-        h.object = __float_as_int(hi.x);
+        h.normal = normalize(h.point - xyz(ea));
+        h.object = sk_payload(sk);
         h.u = pm_atan2f(h.normal.x, h.normal.z) / (2 * 3.14159265358979323846264338327950288f) + 0.5f;
         h.v = h.normal.y * 0.5f + 0.5f;
     } else if (kind == rt::ENT_CUBE) {
         float t; V3 n;
-        const V3 mn = xyz(lo), mx = xyz(hi);
+        const V3 mn = xyz(ea), mx = mk(ea.w, eb.x, eb.y);
         cube_test(mn, mx, ray, t, n);
         h.normal = n;
-        h.object = __float_as_int(lo.w);
+        h.object = sk_payload(sk);
         h.point = ray.o + ray.d * t;
         h.point = h.point + n * 0.02f;
         const V3 m01 = mk((h.point.x - mn.x) / (mx.x - mn.x), (h.point.y - mn.y) / (mx.y - mn.y), (h.point.z - mn.z) / (mx.z - mn.z));
@@ -482,7 +614,7 @@ __device__ inline void finalize_hit(const Scene& sc, const Ray& ray, const Close
         const float4* I = sc.inst + (size_t)c.inst * rt::RT_INST_F4;
         const float4 i0 = I[0], i1 = I[1], i2 = I[2], i3 = I[3];
         const Ray q = to_instance(i0, i1, i2, ray);
-        const float4* T = sc.tris + (size_t)__float_as_int(lo.x) * rt::RT_TRI_F4;
+        const float4* T = sc.tris + (size_t)sk_payload(sk) * rt::RT_TRI_F4;
         const V3 n = mk(T[4].z, T[4].w, T[5].x);
         const V3 hp = q.o + q.d * c.dist;
         h.point = hp + n * 0.01f;

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
     const int lane = (int)(threadIdx.x & 63u);
     const unsigned long long below = (1ull << lane) - 1ull;
     Walker w;
-    w.busy = false; w.kind = K_END;
+    walker_idle(sc, w);
     uint32_t my_idx = 0;
     // the wave owns queue positions [mine, mine_end); it reserves CHUNK more with one atomic when they run out
     uint32_t mine = 0, mine_end = 0;
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
     chunk = chunk < 64u ? 64u : (chunk > (uint32_t)tune.chunk ? (uint32_t)tune.chunk : chunk);
     bool drained = false;   // wave-uniform: every queue position has been handed out
     for (;;) {
-        const unsigned long long idle = __ballot(!w.busy);
+        const unsigned long long idle = __ballot(walker_is_idle(w));
         if (!drained && __popcll(idle) >= tune.refill_at) {
             if (mine == mine_end) {
                 uint32_t base = 0;
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
             if (mine == mine_end) drained = true;
             else {
                 const uint32_t idx = mine + (uint32_t)__popcll(idle & below);
-                if (!w.busy && idx < mine_end) {
+                if (walker_is_idle(w) && idx < mine_end) {
                     Ray ray; Rng rng; uint32_t slot, depth;
                     if (fetch_ray<FIRST>(cam, g, bt, q, qin, dbg, idx, ray, rng, slot, depth)) {
                         my_idx = idx;
@@ -172,11 +172,11 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
                 mine = mine + took < mine_end ? mine + took : mine_end;
             }
         }
-        if (!__any(w.busy)) {
+        if (!__any(!walker_is_idle(w))) {
             if (drained) break;
             continue;
         }
-        if (walk_round(sc, st, w, tune.quorum)) {
+        if (walk_round<STAGED>(sc, st, w, tune.quorum)) {
             q.hit[my_idx] = make_float4(w.c.dist, __int_as_float(w.c.best), w.c.u, w.c.v);
             q.hit_inst[my_idx] = w.c.inst;
         }
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void trace_kernel(Scene sc, int n, const float
     Store st;
     st.ent = sc.ent; st.tris = sc.tris;
     Walker w;
-    w.busy = false; w.kind = K_END;
+    walker_idle(sc, w);
     Ray r;
     r.o = mk(0, 0, 0); r.d = mk(0, 0, 1);
     if (i < n) {
@@ -577,8 +577,27 @@ int rt_engine_set_scene(rt_engine* e, const rt_scene* s) {
     float4 *ent, *tris, *inst, *objects, *planes;
     rt::ImageRec* images;
     uint8_t* texels;
-    std::vector<rt::F4> inter(f->ent_lo.size() * 2);   // lo and hi of an entry side by side: one 32-byte fetch
-    for (size_t i = 0; i < f->ent_lo.size(); i++) { inter[2 * i] = f->ent_lo[i]; inter[2 * i + 1] = f->ent_hi[i]; }
+    // device entries (layout: rt_flat.h), 8 dwords each
+    if (f->ent_lo.size() > rt::SK_MASK || f->objects.size() / rt::RT_OBJ_F4 > rt::SK_MASK) return fail(RT_E_INVALID, "scene too large: more than 2^28 entries or objects");
+    std::vector<rt::F4> inter(f->ent_lo.size() * 2);
+    for (size_t i = 0; i < f->ent_lo.size(); i++) {
+        const rt::F4 lo = f->ent_lo[i], hi = f->ent_hi[i];
+        const int kind = rt::bits_i(hi.w);
+        auto tag = [](int k, int payload) { return rt::bits_f((int32_t)(((uint32_t)k << rt::SK_SHIFT) | (uint32_t)payload)); };
+        rt::F4 a{0, 0, 0, 0}, b{0, 0, tag(kind, 0), 0};
+        switch (kind) {
+        case rt::ENT_INNER:
+            a = {lo.x, hi.x, lo.y, hi.y};
+            if (lo.x <= hi.x && lo.y <= hi.y && lo.z <= hi.z) b = {lo.z, hi.z, lo.w, 0};
+            else b = {lo.z, hi.z, tag(rt::ENT_INNER_INV, 0), lo.w};
+            break;
+        case rt::ENT_SPHERE: a = lo; b.z = tag(kind, rt::bits_i(hi.x)); break;
+        case rt::ENT_CUBE: a = {lo.x, lo.y, lo.z, hi.x}; b = {hi.y, hi.z, tag(kind, rt::bits_i(lo.w)), 0}; break;
+        case rt::ENT_TRI: case rt::ENT_INSTANCE: b.z = tag(kind, rt::bits_i(lo.x)); break;
+        default: break;
+        }
+        inter[2 * i] = a; inter[2 * i + 1] = b;
+    }
     if (int rc = upload(&ent, inter.data(), inter.size() * 16)) return rc;
     e->scene_allocs.push_back(ent);
     if (int rc = upload(&tris, f->tris.data(), f->tris.size() * 16)) return rc;
@@ -598,6 +617,7 @@ int rt_engine_set_scene(rt_engine* e, const rt_scene* s) {
     sc.sky_off = f->sky.offset; sc.sky_w = f->sky.w; sc.sky_h = f->sky.h;
     sc.top_end = f->top_end; sc.stale_entry = f->stale_entry; sc.n_planes = (int)f->planes.size();
     sc.n_entries = (int)f->ent_lo.size(); sc.n_tris = (int)f->tris.size() / rt::RT_TRI_F4; sc.fast_div_ok = f->fast_div_ok ? 1 : 0;
+    sc.idle_entry = f->idle_entry;
     e->sc = sc;
     // stage the whole scene in LDS when two 1024-thread blocks per CU can each hold it (160 KiB per CU)
     const size_t need = (inter.size() + f->tris.size()) * 16;

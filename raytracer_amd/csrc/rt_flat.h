@@ -6,12 +6,26 @@
 // (Object.cpp:241-252) visits them.  An inner node carries the index to continue at when its box is missed ("skip"), so
 // traversal needs no stack:  i = box_hit ? i + 1 : skip.   A node whose two children are the same object (span 1,
 // Object.cpp:198-200) lists that object once: testing it twice cannot change the result.
+// Host arrays (rt_scene_flat::ent_lo / ent_hi), one pair of records per entry:
 //   kind INNER    lo = (min.x, min.y, min.z, skip)        hi = (max.x, max.y, max.z, kind)
 //   kind SPHERE   lo = (c.x, c.y, c.z, radius)            hi = (object id, 0, 0, kind)
 //   kind CUBE     lo = (min.x, min.y, min.z, object id)   hi = (max.x, max.y, max.z, kind)
 //   kind TRI      lo = (triangle index, 0, 0, 0)          hi = (0, 0, 0, kind)
 //   kind INSTANCE lo = (instance index, 0, 0, 0)          hi = (0, 0, 0, kind)
-// The top-level list occupies [0, top_end); each mesh instance owns a range [begin, end) after it.
+//   kind END      closes the top-level list and every instance range; kind IDLE is one extra entry that lanes
+//                 without a ray stand on.  A lane therefore always has an entry to load and its kind says what to do.
+// The top-level list occupies [0, top_end], entry top_end being its END; each mesh instance owns a range after it.
+//
+// Device entries (what the engine uploads, 8 dwords): dword 6 = kind << 28 | payload, so that one compare tells inner
+// entries (kind 0) from everything else and an inner entry's dword 6 IS its skip index.
+//   INNER      min.x max.x | min.y max.y | min.z max.z | skip | 0        the bounds of an axis side by side: the operand
+//                                                                        pairs of packed FP32 arithmetic
+//   INNER_INV  same six bounds | kind | skip      a box with min > max on some axis (unions over negative-radius spheres,
+//                                                 Object.cpp:29-35,156-166): tested by the general slab test
+//   SPHERE     c.x c.y c.z radius 0 0 | kind, object id | 0
+//   CUBE       min.xyz max.xyz | kind, object id | 0
+//   TRI        0 0 0 0 0 0 | kind, triangle index | 0          INSTANCE  likewise with the instance index
+//   END, IDLE  0 ... | kind | 0
 //
 // Triangle (RT_TRI_F4 = 6 records):  (v0.xyz, -) (v1.xyz, -) (v2.xyz, -) (uv0.xy, uv1.xy) (uv2.xy, n.x, n.y) (n.z, -, -, -)
 // Instance (RT_INST_F4 = 4):         (offset.xyz, has_move) (pivot.xyz, rot axis or -1) (sin, cos, begin, end)
@@ -26,8 +40,10 @@ namespace rt {
 struct F4 { float x, y, z, w; };
 struct ImageRec { uint32_t offset, w, h, channels; };   // byte offset into the texel pool
 
-enum : int { ENT_INNER = 0, ENT_SPHERE = 1, ENT_CUBE = 2, ENT_TRI = 3, ENT_INSTANCE = 4 };
+enum : int { ENT_INNER = 0, ENT_SPHERE = 1, ENT_CUBE = 2, ENT_TRI = 3, ENT_INSTANCE = 4, ENT_END = 5, ENT_IDLE = 6, ENT_INNER_INV = 7 };
 constexpr int RT_TRI_F4 = 6, RT_INST_F4 = 4, RT_OBJ_F4 = 4;
+constexpr int SK_SHIFT = 28;
+constexpr uint32_t SK_MASK = (1u << SK_SHIFT) - 1u;
 
 inline float bits_f(int32_t i) { union { int32_t i; float f; } u; u.i = i; return u.f; }
 inline int32_t bits_i(float f) { union { int32_t i; float f; } u; u.f = f; return u.i; }

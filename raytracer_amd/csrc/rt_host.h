@@ -55,7 +55,7 @@ struct rt_scene_flat {
     std::vector<rt::ImageRec> images;
     std::vector<uint8_t> texels;             // all images then the skybox, each padded by one row
     rt::ImageRec sky{0, 0, 0, 0};
-    int32_t top_end = 0, stale_entry = -1;
+    int32_t top_end = 0, stale_entry = -1, idle_entry = 0;
     bool fast_div_ok = false;                // every box coordinate is 0 or has magnitude in [2^-50, 2^40] (see rt_device.h, div_by)
 };
 

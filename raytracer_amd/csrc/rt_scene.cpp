@@ -238,6 +238,8 @@ void flatten(rt_scene& s) {
     Flattener fl{s, f};
     fl.emit(s.root, true);
     f.top_end = (int)f.ent_lo.size();
+    f.ent_lo.push_back({0, 0, 0, 0});
+    f.ent_hi.push_back({0, 0, 0, bits_f(ENT_END)});
     f.stale_entry = fl.first_leaf;
     f.inst.resize(fl.pending.size() * RT_INST_F4);
     for (size_t k = 0; k < fl.pending.size(); k++) {
@@ -255,11 +257,16 @@ void flatten(rt_scene& s) {
         Flattener sub{s, f};
         sub.emit(s.objs[idx].root, false);
         const int end = (int)f.ent_lo.size();
+        f.ent_lo.push_back({0, 0, 0, 0});
+        f.ent_hi.push_back({0, 0, 0, bits_f(ENT_END)});
         f.inst[k * RT_INST_F4 + 0] = {offset.x, offset.y, offset.z, has_move};
         f.inst[k * RT_INST_F4 + 1] = {pivot.x, pivot.y, pivot.z, bits_f(axis)};
         f.inst[k * RT_INST_F4 + 2] = {sin_t, cos_t, bits_f(begin), bits_f(end)};
         f.inst[k * RT_INST_F4 + 3] = {bits_f(id), bits_f(sub.first_leaf), 0, 0};
     }
+    f.idle_entry = (int)f.ent_lo.size();
+    f.ent_lo.push_back({0, 0, 0, 0});
+    f.ent_hi.push_back({0, 0, 0, bits_f(ENT_IDLE)});
     f.fast_div_ok = true;
     for (size_t i = 0; i < f.ent_lo.size(); i++) {
         if (bits_i(f.ent_hi[i].w) != ENT_INNER) continue;
