@@ -129,7 +129,7 @@ struct Scene {
     const rt::ImageRec* images; const uint8_t* texels;
     uint32_t sky_off, sky_w, sky_h;
     int top_end, stale_entry, n_planes;
-    int n_entries, n_tris, fast_div_ok, idle_entry;
+    int n_entries, n_tris, n_inst, fast_div_ok, idle_entry;
 };
 struct Ray { V3 o, d; };
 
@@ -246,23 +246,28 @@ __device__ __forceinline__ bool tri_test(const Scene& sc, const float4* tris, in
     return true;
 }
 
+// The rotation of RotationIntersect (Object.cpp:306-316 in, :322-333 out) about one axis: components (a1, a2) = (1,2) for
+// X, (0,2) for Y, (0,1) for Z are mixed, the third is kept.  Written per axis with plain components: a run-time index
+// into a register-resident vector would push it out to scratch memory.
+__device__ __forceinline__ V3 rotate_in(int axis, float sinT, float cosT, V3 v) {
+    if (axis == 0) return mk(v.x, cosT * v.y - sinT * v.z, sinT * v.y + cosT * v.z);
+    if (axis == 1) return mk(cosT * v.x - sinT * v.z, v.y, sinT * v.x + cosT * v.z);
+    return mk(cosT * v.x - sinT * v.y, sinT * v.x + cosT * v.y, v.z);
+}
+__device__ __forceinline__ V3 rotate_out(int axis, float sinT, float cosT, V3 v) {
+    if (axis == 0) return mk(v.x, cosT * v.y + sinT * v.z, -sinT * v.y + cosT * v.z);
+    if (axis == 1) return mk(cosT * v.x + sinT * v.z, v.y, -sinT * v.x + cosT * v.z);
+    return mk(cosT * v.x + sinT * v.y, -sinT * v.x + cosT * v.y, v.z);
+}
 // ApplyMovement::Intersect + RotationIntersect on the way in (Object.cpp:601-603, 306-316)
 __device__ __forceinline__ Ray to_instance(const float4 i0, const float4 i1, const float4 i2, const Ray& r) {
     Ray q = r;
     if (i0.w != 0.0f) q.o = r.o - xyz(i0);
     const int axis = __float_as_int(i1.w);
     if (axis >= 0) {
-        const int a1 = axis == 0 ? 1 : 0, a2 = axis == 2 ? 1 : 2;
-        const float sinT = i2.x, cosT = i2.y;
         const V3 pivot = xyz(i1);
-        const V3 oo = q.o - pivot;
-        V3 om = oo, dir = q.d;
-        setc(om, a1, cosT * comp(oo, a1) - sinT * comp(oo, a2));
-        setc(om, a2, sinT * comp(oo, a1) + cosT * comp(oo, a2));
-        setc(dir, a1, cosT * comp(q.d, a1) - sinT * comp(q.d, a2));
-        setc(dir, a2, sinT * comp(q.d, a1) + cosT * comp(q.d, a2));
-        q.o = om + pivot;
-        q.d = dir;
+        q.o = rotate_in(axis, i2.x, i2.y, q.o - pivot) + pivot;
+        q.d = rotate_in(axis, i2.x, i2.y, q.d);
     }
     return q;
 }
@@ -270,17 +275,9 @@ __device__ __forceinline__ Ray to_instance(const float4 i0, const float4 i1, con
 __device__ __forceinline__ void from_instance(const float4 i0, const float4 i1, const float4 i2, V3& point, V3& normal) {
     const int axis = __float_as_int(i1.w);
     if (axis >= 0) {
-        const int a1 = axis == 0 ? 1 : 0, a2 = axis == 2 ? 1 : 2;
-        const float sinT = i2.x, cosT = i2.y;
         const V3 pivot = xyz(i1);
-        const V3 oo = point - pivot;
-        V3 om = oo, n = normal;
-        setc(om, a1, cosT * comp(oo, a1) + sinT * comp(oo, a2));
-        setc(om, a2, -sinT * comp(oo, a1) + cosT * comp(oo, a2));
-        setc(n, a1, cosT * comp(normal, a1) + sinT * comp(normal, a2));
-        setc(n, a2, -sinT * comp(normal, a1) + cosT * comp(normal, a2));
-        point = om + pivot;
-        normal = n;
+        point = rotate_out(axis, i2.x, i2.y, point - pivot) + pivot;
+        normal = rotate_out(axis, i2.x, i2.y, normal);
     }
     if (i0.w != 0.0f) point = point + xyz(i0);
 }
@@ -322,18 +319,21 @@ __device__ __forceinline__ int sk_payload(uint32_t sk) { return (int)(sk & rt::S
 // on inner entries step together (box tests), lanes on leaves test primitives together.  A lane without a ray stands on
 // the scene's IDLE entry.
 struct Walker {
-    Ray top;                 // the ray as given
-    // the ray in the current (instance) frame, kept as the operand pairs of the box step:
+    // the ray in the current frame (the scene's, or a mesh instance's), kept as the operand pairs of the box step:
     // (o.x, o.y) (o.z, 1/d.x) (1/d.y, 1/d.z) (d.x, d.y) (d.z, -)
     f2 p0, p1, p2, p3, p4;
     bool usable;             // the reciprocal path reproduces true division for this ray
+    // while inside an instance: the same for the ray as given, to come back to
+    f2 s0, s1, s2, s3, s4;
+    bool s_usable;
     int i, resume, inst, stale, alpha_img;
     f2 e01, e23, e45;        // dwords 0..5 of the entry
     uint32_t sk;             // dword 6: kind << 28 | payload; for an inner entry (kind 0) simply the skip index
+    uint32_t f0, f1, f2, cnt;   // leaves visited but not yet tested, oldest first, and their number (0..3)
     Closest c;
 };
 // entries (and, when staged, triangles) either in LDS or in global memory
-struct Store { const float4* ent; const float4* tris; };   // 2 x float4 per entry
+struct Store { const float4* ent; const float4* tris; const float4* inst; };   // 2 x float4 per entry
 
 __device__ __forceinline__ Ray walker_ray(const Walker& w) {
     Ray r;
@@ -353,26 +353,35 @@ __device__ __forceinline__ void walker_load(const Store& st, Walker& w) {
 __device__ __forceinline__ void walker_idle(const Scene& sc, Walker& w) {
     w.i = sc.idle_entry; w.sk = (uint32_t)rt::ENT_IDLE << rt::SK_SHIFT;
     w.e01 = f2{0, 0}; w.e23 = f2{0, 0}; w.e45 = f2{0, 0};
-    w.top.o = mk(0, 0, 0); w.top.d = mk(0, 0, 1);
     w.p0 = f2{0, 0}; w.p1 = f2{0, 1}; w.p2 = f2{1, 1}; w.p3 = f2{1, 1}; w.p4 = f2{1, 0}; w.usable = true;
+    w.s0 = w.p0; w.s1 = w.p1; w.s2 = w.p2; w.s3 = w.p3; w.s4 = w.p4; w.s_usable = true;
     w.resume = 0; w.inst = -1; w.stale = -1; w.alpha_img = -1;
+    w.f0 = 0; w.f1 = 0; w.f2 = 0; w.cnt = 0;
     w.c.dist = FLT_MAX; w.c.best = -1; w.c.inst = -1; w.c.u = 0; w.c.v = 0; w.c.hit = false;
 }
 __device__ __forceinline__ void walker_start(const Scene& sc, const Store& st, Walker& w, const Ray& ray) {
-    w.top = ray;
     walker_set_ray(w, ray, sc.fast_div_ok != 0);
     w.i = 0; w.resume = 0; w.inst = -1; w.stale = sc.stale_entry; w.alpha_img = -1;
+    w.f0 = 0; w.f1 = 0; w.f2 = 0; w.cnt = 0;
     w.c.dist = FLT_MAX; w.c.best = -1; w.c.inst = -1; w.c.u = 0; w.c.v = 0; w.c.hit = false;
     walker_load(st, w);
 }
 
-// BVH_Node::Intersect (Object.cpp:241-252) on inner entries — BoundingBox::DoesRayHit (DataUtility.cpp:35-82), then into
-// the left subtree or past the whole subtree:  i = hit ? i + 1 : skip, fetch entry i  — repeated for the lanes of the
-// wave that stand on an inner entry (and whose ray is admitted to the reciprocal path) for as long as at least
-// `quorum` lanes do, plus one last step for the stragglers.
+// The traversal loop.  BVH_Node::Intersect (Object.cpp:241-252) visits both children of every node whose box is hit, no
+// matter what the primitives below return, so the sequence of entries a ray visits does not depend on any primitive
+// test.  A lane therefore does not stop at a leaf: it notes the leaf in a short per-lane FIFO (f0, f1, f2; oldest
+// first) and walks on; the primitive tests are run later, in visiting order, with many lanes at once (prim_step).
 //
-// This loop is the instruction stream the renderer spends most of its time in, so it is written out by hand: 33 vector
-// instructions per step where the compiler's schedule of the same arithmetic needs 50 to 70 (it keeps the entry in
+// One iteration, for the lanes of the wave that can move:
+//   * lanes on an inner entry whose ray is admitted to the reciprocal path: BoundingBox::DoesRayHit
+//     (DataUtility.cpp:35-82), then  i = hit ? i + 1 : skip;
+//   * lanes on a sphere / cube / triangle entry with room in their FIFO: note i, then i = i + 1;
+//   * both: fetch entry i.
+// It repeats while at least `quorum` lanes stand on inner entries (and runs once more for the stragglers).  Lanes on
+// anything else (END, INSTANCE, boxes or rays that need the general test, a full FIFO) wait for the caller.
+//
+// This is the instruction stream the renderer spends most of its time in, so it is written out by hand: 33 vector
+// instructions per box step where the compiler's schedule of the same arithmetic needs 50 to 70 (it keeps the entry in
 // four-register tuples, rebuilds operand pairs and copies loop-carried values around the loop).
 //   * the entry holds the bounds of an axis side by side (min.x, max.x) (min.y, max.y) (min.z, max.z): one packed
 //     subtract, multiply and four packed FMAs per axis give both quotients (div_by above, two lanes wide); per-ray
@@ -385,145 +394,217 @@ __device__ __forceinline__ void walker_start(const Scene& sc, const Store& st, W
 //     the last test, both distances negative (:78), is then "exit < 0".  Entry/exit per axis are picked by the sign of
 //     the direction (px, py, pz: lane masks of d >= 0), as the reference does;
 //   * the loads land in the registers that already hold the entry (tied operands): nothing is copied;
-//   * the lanes that take a step are enabled through exec inside the block (restored before every test and at the
-//     end), so the surrounding control flow is wave-uniform.
-// v2..v8 are used as scratch registers by name because the halves of a register pair cannot be named through operands.
+//   * the lanes that act are enabled through exec inside the block (restored before every test and at the end), so the
+//     surrounding control flow is wave-uniform.
+// v2..v21 are used as scratch registers by name because the halves of a register pair cannot be named through operands.
 // Every lane of the wave must be enabled at the call.
 template <bool LDS>
 __device__ __forceinline__ void box_steps(const Store& st, Walker& w, int quorum) {
     const unsigned long long px = __ballot(w.p3.x >= 0), py = __ballot(w.p3.y >= 0), pz = __ballot(w.p4.x >= 0);
-    const unsigned long long usable = __ballot(w.usable), saved = __ballot(true);
-    f2 t0, t1, t2, r0, r1, r2;
-    unsigned long long m, m2;
-    int cnt;
+    const unsigned long long usable = __ballot(w.usable);
+    unsigned long long m, m2, m3, mall, saved;
+    int n_inner;
     if (LDS) {
         const uint32_t base = (uint32_t)(uintptr_t)st.ent;   // LDS addresses are 32-bit offsets
         asm volatile(
+                 "s_mov_b64 %13, exec\n\t"
                  "1:\n\t"
                  "v_cmp_gt_u32_e32 vcc, 0x10000000, %3\n\t"
-                 "s_and_b64 %11, vcc, %23\n\t"
-                 "s_cmp_eq_u64 %11, 0\n\t"
+                 "s_and_b64 %9, vcc, %24\n\t"
+                 "v_add_u32_e32 v9, 0xf0000000, %3\n\t"
+                 "v_cmp_gt_u32_e64 %10, 3, %8\n\t"
+                 "v_cmp_gt_u32_e32 vcc, 0x30000000, v9\n\t"
+                 "s_and_b64 %10, %10, vcc\n\t"
+                 "s_or_b64 %12, %9, %10\n\t"
+                 "s_cmp_eq_u64 %12, 0\n\t"
                  "s_cbranch_scc1 2f\n\t"
-                 "s_and_b64 exec, %25, %11\n\t"
-                 "v_pk_add_f32 %5, %0, %14 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-                 "v_pk_add_f32 %6, %1, %14 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-                 "v_pk_add_f32 %7, %2, %15 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-                 "v_pk_mul_f32 v[2:3], %5, %15 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
-                 "v_pk_mul_f32 v[4:5], %6, %16 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
-                 "v_pk_mul_f32 v[6:7], %7, %16 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
-                 "v_pk_fma_f32 %8, %17, v[2:3], %5 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 %9, %17, v[4:5], %6 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 %10, %18, v[6:7], %7 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 v[2:3], %8, %15, v[2:3] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                 "v_pk_fma_f32 v[4:5], %9, %16, v[4:5] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
-                 "v_pk_fma_f32 v[6:7], %10, %16, v[6:7] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                 "v_pk_fma_f32 %8, %17, v[2:3], %5 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 %9, %17, v[4:5], %6 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 %10, %18, v[6:7], %7 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 v[2:3], %8, %15, v[2:3] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                 "v_pk_fma_f32 v[4:5], %9, %16, v[4:5] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
-                 "v_pk_fma_f32 v[6:7], %10, %16, v[6:7] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                 "v_cndmask_b32_e64 v8, v3, v2, %19\n\t"
-                 "v_cndmask_b32_e64 v3, v2, v3, %19\n\t"
-                 "v_cndmask_b32_e64 v2, v5, v4, %20\n\t"
-                 "v_cndmask_b32_e64 v5, v4, v5, %20\n\t"
-                 "v_cndmask_b32_e64 v4, v7, v6, %21\n\t"
-                 "v_cndmask_b32_e64 v7, v6, v7, %21\n\t"
+                 "s_cmp_eq_u64 %9, 0\n\t"
+                 "s_cbranch_scc1 3f\n\t"
+                 "s_and_b64 exec, %13, %9\n\t"
+                 "v_pk_add_f32 v[10:11], %0, %15 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                 "v_pk_add_f32 v[12:13], %1, %15 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                 "v_pk_add_f32 v[14:15], %2, %16 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                 "v_pk_mul_f32 v[2:3], v[10:11], %16 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                 "v_pk_mul_f32 v[4:5], v[12:13], %17 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+                 "v_pk_mul_f32 v[6:7], v[14:15], %17 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                 "v_pk_fma_f32 v[16:17], %18, v[2:3], v[10:11] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[18:19], %18, v[4:5], v[12:13] op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[20:21], %19, v[6:7], v[14:15] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[2:3], v[16:17], %16, v[2:3] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 v[4:5], v[18:19], %17, v[4:5] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 v[6:7], v[20:21], %17, v[6:7] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 v[16:17], %18, v[2:3], v[10:11] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[18:19], %18, v[4:5], v[12:13] op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[20:21], %19, v[6:7], v[14:15] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[2:3], v[16:17], %16, v[2:3] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 v[4:5], v[18:19], %17, v[4:5] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 v[6:7], v[20:21], %17, v[6:7] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_cndmask_b32_e64 v8, v3, v2, %20\n\t"
+                 "v_cndmask_b32_e64 v3, v2, v3, %20\n\t"
+                 "v_cndmask_b32_e64 v2, v5, v4, %21\n\t"
+                 "v_cndmask_b32_e64 v5, v4, v5, %21\n\t"
+                 "v_cndmask_b32_e64 v4, v7, v6, %22\n\t"
+                 "v_cndmask_b32_e64 v7, v6, v7, %22\n\t"
                  "v_max3_f32 v8, v8, v2, v4\n\t"
                  "v_min3_f32 v3, v3, v5, v7\n\t"
                  "v_cmp_le_f32_e32 vcc, v8, v3\n\t"
-                 "v_cmp_nlt_f32_e64 %12, v3, 0\n\t"
+                 "v_cmp_nlt_f32_e64 %11, v3, 0\n\t"
                  "v_add_u32_e32 v2, 1, %4\n\t"
-                 "s_and_b64 vcc, vcc, %12\n\t"
-                 "s_bcnt1_i32_b64 %13, %11\n\t"
+                 "s_and_b64 vcc, vcc, %11\n\t"
+                 "s_nop 0\n\t"
                  "v_cndmask_b32_e32 %4, %3, v2, vcc\n\t"
-                 "v_lshl_add_u32 v2, %4, 5, %22\n\t"
+                 "3:\n\t"
+                 "s_cmp_eq_u64 %10, 0\n\t"
+                 "s_cbranch_scc1 4f\n\t"
+                 "s_and_b64 exec, %13, %10\n\t"
+                 "v_cmp_eq_u32_e64 %11, 0, %8\n\t"
+                 "v_cmp_eq_u32_e32 vcc, 1, %8\n\t"
+                 "v_mov_b32_e32 %7, %4\n\t"
+                 "v_add_u32_e32 %8, 1, %8\n\t"
+                 "v_cndmask_b32_e64 %5, %5, %4, %11\n\t"
+                 "v_cndmask_b32_e32 %6, %6, %4, vcc\n\t"
+                 "v_add_u32_e32 %4, 1, %4\n\t"
+                 "4:\n\t"
+                 "s_and_b64 exec, %13, %12\n\t"
+                 "v_lshl_add_u32 v2, %4, 5, %23\n\t"
                  "ds_read_b64 %0, v2\n\t"
                  "ds_read_b64 %1, v2 offset:8\n\t"
                  "ds_read_b64 %2, v2 offset:16\n\t"
                  "ds_read_b32 %3, v2 offset:24\n\t"
                  "s_waitcnt lgkmcnt(0)\n\t"
-                 "s_mov_b64 exec, %25\n\t"
-                 "s_cmp_ge_u32 %13, %24\n\t"
+                 "s_mov_b64 exec, %13\n\t"
+                 "s_bcnt1_i32_b64 %14, %9\n\t"
+                 "s_cmp_ge_u32 %14, %25\n\t"
                  "s_cbranch_scc1 1b\n\t"
                  "2:\n\t"
-                 : "+v"(w.e01), "+v"(w.e23), "+v"(w.e45), "+v"(w.sk), "+v"(w.i),
-                   "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&s"(m), "=&s"(m2), "=&s"(cnt)
+                 : "+v"(w.e01), "+v"(w.e23), "+v"(w.e45), "+v"(w.sk), "+v"(w.i), "+v"(w.f0), "+v"(w.f1), "+v"(w.f2), "+v"(w.cnt),
+                   "=&s"(m), "=&s"(m2), "=&s"(m3), "=&s"(mall), "=&s"(saved), "=&s"(n_inner)
                  : "v"(w.p0), "v"(w.p1), "v"(w.p2), "v"(w.p3), "v"(w.p4), "s"(px), "s"(py), "s"(pz), "s"(base), "s"(usable),
-                   "s"(quorum), "s"(saved)
-                 : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "vcc", "scc", "memory");
+                   "s"(quorum)
+                 : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18",
+                   "v19", "v20", "v21", "vcc", "scc", "memory");
     } else {
         const float4* base = st.ent;
         asm volatile(
+                 "s_mov_b64 %13, exec\n\t"
                  "1:\n\t"
                  "v_cmp_gt_u32_e32 vcc, 0x10000000, %3\n\t"
-                 "s_and_b64 %11, vcc, %23\n\t"
-                 "s_cmp_eq_u64 %11, 0\n\t"
+                 "s_and_b64 %9, vcc, %24\n\t"
+                 "v_add_u32_e32 v9, 0xf0000000, %3\n\t"
+                 "v_cmp_gt_u32_e64 %10, 3, %8\n\t"
+                 "v_cmp_gt_u32_e32 vcc, 0x30000000, v9\n\t"
+                 "s_and_b64 %10, %10, vcc\n\t"
+                 "s_or_b64 %12, %9, %10\n\t"
+                 "s_cmp_eq_u64 %12, 0\n\t"
                  "s_cbranch_scc1 2f\n\t"
-                 "s_and_b64 exec, %25, %11\n\t"
-                 "v_pk_add_f32 %5, %0, %14 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-                 "v_pk_add_f32 %6, %1, %14 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-                 "v_pk_add_f32 %7, %2, %15 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-                 "v_pk_mul_f32 v[2:3], %5, %15 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
-                 "v_pk_mul_f32 v[4:5], %6, %16 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
-                 "v_pk_mul_f32 v[6:7], %7, %16 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
-                 "v_pk_fma_f32 %8, %17, v[2:3], %5 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 %9, %17, v[4:5], %6 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 %10, %18, v[6:7], %7 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 v[2:3], %8, %15, v[2:3] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                 "v_pk_fma_f32 v[4:5], %9, %16, v[4:5] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
-                 "v_pk_fma_f32 v[6:7], %10, %16, v[6:7] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                 "v_pk_fma_f32 %8, %17, v[2:3], %5 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 %9, %17, v[4:5], %6 op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 %10, %18, v[6:7], %7 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 v[2:3], %8, %15, v[2:3] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                 "v_pk_fma_f32 v[4:5], %9, %16, v[4:5] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
-                 "v_pk_fma_f32 v[6:7], %10, %16, v[6:7] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                 "v_cndmask_b32_e64 v8, v3, v2, %19\n\t"
-                 "v_cndmask_b32_e64 v3, v2, v3, %19\n\t"
-                 "v_cndmask_b32_e64 v2, v5, v4, %20\n\t"
-                 "v_cndmask_b32_e64 v5, v4, v5, %20\n\t"
-                 "v_cndmask_b32_e64 v4, v7, v6, %21\n\t"
-                 "v_cndmask_b32_e64 v7, v6, v7, %21\n\t"
+                 "s_cmp_eq_u64 %9, 0\n\t"
+                 "s_cbranch_scc1 3f\n\t"
+                 "s_and_b64 exec, %13, %9\n\t"
+                 "v_pk_add_f32 v[10:11], %0, %15 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                 "v_pk_add_f32 v[12:13], %1, %15 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                 "v_pk_add_f32 v[14:15], %2, %16 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                 "v_pk_mul_f32 v[2:3], v[10:11], %16 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                 "v_pk_mul_f32 v[4:5], v[12:13], %17 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+                 "v_pk_mul_f32 v[6:7], v[14:15], %17 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                 "v_pk_fma_f32 v[16:17], %18, v[2:3], v[10:11] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[18:19], %18, v[4:5], v[12:13] op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[20:21], %19, v[6:7], v[14:15] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[2:3], v[16:17], %16, v[2:3] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 v[4:5], v[18:19], %17, v[4:5] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 v[6:7], v[20:21], %17, v[6:7] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 v[16:17], %18, v[2:3], v[10:11] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[18:19], %18, v[4:5], v[12:13] op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[20:21], %19, v[6:7], v[14:15] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[2:3], v[16:17], %16, v[2:3] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 v[4:5], v[18:19], %17, v[4:5] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 v[6:7], v[20:21], %17, v[6:7] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_cndmask_b32_e64 v8, v3, v2, %20\n\t"
+                 "v_cndmask_b32_e64 v3, v2, v3, %20\n\t"
+                 "v_cndmask_b32_e64 v2, v5, v4, %21\n\t"
+                 "v_cndmask_b32_e64 v5, v4, v5, %21\n\t"
+                 "v_cndmask_b32_e64 v4, v7, v6, %22\n\t"
+                 "v_cndmask_b32_e64 v7, v6, v7, %22\n\t"
                  "v_max3_f32 v8, v8, v2, v4\n\t"
                  "v_min3_f32 v3, v3, v5, v7\n\t"
                  "v_cmp_le_f32_e32 vcc, v8, v3\n\t"
-                 "v_cmp_nlt_f32_e64 %12, v3, 0\n\t"
+                 "v_cmp_nlt_f32_e64 %11, v3, 0\n\t"
                  "v_add_u32_e32 v2, 1, %4\n\t"
-                 "s_and_b64 vcc, vcc, %12\n\t"
-                 "s_bcnt1_i32_b64 %13, %11\n\t"
+                 "s_and_b64 vcc, vcc, %11\n\t"
+                 "s_nop 0\n\t"
                  "v_cndmask_b32_e32 %4, %3, v2, vcc\n\t"
+                 "3:\n\t"
+                 "s_cmp_eq_u64 %10, 0\n\t"
+                 "s_cbranch_scc1 4f\n\t"
+                 "s_and_b64 exec, %13, %10\n\t"
+                 "v_cmp_eq_u32_e64 %11, 0, %8\n\t"
+                 "v_cmp_eq_u32_e32 vcc, 1, %8\n\t"
+                 "v_mov_b32_e32 %7, %4\n\t"
+                 "v_add_u32_e32 %8, 1, %8\n\t"
+                 "v_cndmask_b32_e64 %5, %5, %4, %11\n\t"
+                 "v_cndmask_b32_e32 %6, %6, %4, vcc\n\t"
+                 "v_add_u32_e32 %4, 1, %4\n\t"
+                 "4:\n\t"
+                 "s_and_b64 exec, %13, %12\n\t"
                  "v_lshlrev_b32_e32 v2, 5, %4\n\t"
-                 "global_load_dwordx2 %0, v2, %22\n\t"
-                 "global_load_dwordx2 %1, v2, %22 offset:8\n\t"
-                 "global_load_dwordx2 %2, v2, %22 offset:16\n\t"
-                 "global_load_dword %3, v2, %22 offset:24\n\t"
+                 "global_load_dwordx2 %0, v2, %23\n\t"
+                 "global_load_dwordx2 %1, v2, %23 offset:8\n\t"
+                 "global_load_dwordx2 %2, v2, %23 offset:16\n\t"
+                 "global_load_dword %3, v2, %23 offset:24\n\t"
                  "s_waitcnt vmcnt(0)\n\t"
-                 "s_mov_b64 exec, %25\n\t"
-                 "s_cmp_ge_u32 %13, %24\n\t"
+                 "s_mov_b64 exec, %13\n\t"
+                 "s_bcnt1_i32_b64 %14, %9\n\t"
+                 "s_cmp_ge_u32 %14, %25\n\t"
                  "s_cbranch_scc1 1b\n\t"
                  "2:\n\t"
-                 : "+v"(w.e01), "+v"(w.e23), "+v"(w.e45), "+v"(w.sk), "+v"(w.i),
-                   "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&s"(m), "=&s"(m2), "=&s"(cnt)
+                 : "+v"(w.e01), "+v"(w.e23), "+v"(w.e45), "+v"(w.sk), "+v"(w.i), "+v"(w.f0), "+v"(w.f1), "+v"(w.f2), "+v"(w.cnt),
+                   "=&s"(m), "=&s"(m2), "=&s"(m3), "=&s"(mall), "=&s"(saved), "=&s"(n_inner)
                  : "v"(w.p0), "v"(w.p1), "v"(w.p2), "v"(w.p3), "v"(w.p4), "s"(px), "s"(py), "s"(pz), "s"(base), "s"(usable),
-                   "s"(quorum), "s"(saved)
-                 : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "vcc", "scc", "memory");
+                   "s"(quorum)
+                 : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18",
+                   "v19", "v20", "v21", "vcc", "scc", "memory");
     }
 }
 
-// one leaf-level action.  Returns true when the ray has finished (closest hit known, plane list merged); the lane is
-// idle from then on.
-__device__ __forceinline__ bool walker_leaf(const Scene& sc, const Store& st, Walker& w) {
+// The oldest noted leaf of the lane: Sphere / AxisAlignedCube / Triangle ::Intersect and the closest-hit bookkeeping of
+// BVH_Node::Intersect (Object.cpp:245-251) and World::GetRayColor (World.cpp:110-118).
+__device__ __forceinline__ void prim_step(const Scene& sc, const Store& st, Walker& w) {
+    const int e = (int)w.f0;
+    w.f0 = w.f1; w.f1 = w.f2; w.cnt--;
+    const f2* E = reinterpret_cast<const f2*>(st.ent) + 4 * (size_t)e;
+    const uint32_t sk = reinterpret_cast<const uint32_t*>(E)[6];
+    const int kind = sk_kind(sk);
+    const Ray cur = walker_ray(w);
+    float t = 0, u = 0, v = 0;
+    bool ok, wrote = false;
+    if (kind == rt::ENT_TRI) ok = tri_test(sc, st.tris, sk_payload(sk), w.alpha_img, cur, t, u, v, wrote);
+    else {
+        const f2 a = E[0], b = E[1], c = E[2];
+        if (kind == rt::ENT_SPHERE) ok = sphere_test(mk(a.x, a.y, b.x), b.y, cur, t, wrote);
+        else { V3 n; ok = cube_test(mk(a.x, a.y, b.x), mk(b.y, c.x, c.y), cur, t, n); }
+    }
+    // selects rather than branches around the updates: the record stays in registers
+    const bool better = ok && (!w.c.hit || t < w.c.dist);
+    const bool stale = !ok && wrote && e == w.stale;
+    w.c.dist = (better || stale) ? t : w.c.dist;
+    w.c.best = better ? e : w.c.best;
+    w.c.inst = better ? w.inst : w.c.inst;
+    w.c.u = better ? u : w.c.u;
+    w.c.v = better ? v : w.c.v;
+    w.c.hit = w.c.hit || better;
+}
+// Entries that change the lane's state beyond its position; they wait until every noted leaf has been tested.  Returns
+// true when the ray has finished (closest hit known, plane list merged); the lane is idle from then on.
+__device__ __forceinline__ bool walker_special(const Scene& sc, const Store& st, Walker& w) {
     bool done = false;
     const int kind = sk_kind(w.sk);
-    const Ray cur = walker_ray(w);
     if (kind == rt::ENT_END) {
         if (w.inst >= 0) {   // PolygonMesh and its wrappers return to the top level
             w.i = w.resume; w.inst = -1; w.stale = sc.stale_entry;
-            walker_set_ray(w, w.top, sc.fast_div_ok != 0);
+            w.p0 = w.s0; w.p1 = w.s1; w.p2 = w.s2; w.p3 = w.s3; w.p4 = w.s4; w.usable = w.s_usable;
         } else {
+            const Ray top = walker_ray(w);
             for (int p = 0; p < sc.n_planes; p++) {   // YPlane::Intersect (Object.cpp:139-149), merged as World.cpp:110-118
-                const float t = -(w.top.o.y - sc.planes[p].x) / w.top.d.y;
+                const float t = -(top.o.y - sc.planes[p].x) / top.d.y;
                 if (t < 0.001f) continue;             // "t < 1e-3" against a double: the same floats pass
                 if (t < w.c.dist) { w.c.hit = true; w.c.dist = t; w.c.best = -(p + 2); w.c.inst = -1; }
             }
@@ -532,48 +613,60 @@ __device__ __forceinline__ bool walker_leaf(const Scene& sc, const Store& st, Wa
         }
     } else if (kind == rt::ENT_INSTANCE) {
         const int ii = sk_payload(w.sk);
-        const float4* I = sc.inst + (size_t)ii * rt::RT_INST_F4;
+        const float4* I = st.inst + (size_t)ii * rt::RT_INST_F4;
         const float4 i0 = I[0], i1 = I[1], i2 = I[2], i3 = I[3];
-        walker_set_ray(w, to_instance(i0, i1, i2, w.top), sc.fast_div_ok != 0);
+        w.s0 = w.p0; w.s1 = w.p1; w.s2 = w.p2; w.s3 = w.p3; w.s4 = w.p4; w.s_usable = w.usable;
+        walker_set_ray(w, to_instance(i0, i1, i2, walker_ray(w)), sc.fast_div_ok != 0);
         w.resume = w.i + 1;
         w.stale = (w.i == sc.stale_entry) ? __float_as_int(i3.y) : -1;
         w.inst = ii;
-        const float4 ob = sc.objects[(size_t)__float_as_int(i3.x) * rt::RT_OBJ_F4];
-        w.alpha_img = __float_as_int(ob.y) == 2 ? __float_as_int(ob.z) : -1;
+        w.alpha_img = __float_as_int(i3.z);   // image whose alpha channel cuts the mesh out, or -1
         w.i = __float_as_int(i2.z);
-    } else if (kind == rt::ENT_INNER || kind == rt::ENT_INNER_INV) {
-        // the reference's test as written, with true divisions: a box with min > max on some axis, or a ray that is
-        // not admitted to the reciprocal path
-        const int skip = kind == rt::ENT_INNER ? (int)w.sk : __float_as_int(reinterpret_cast<const float*>(st.ent)[8 * (size_t)w.i + 7]);
-        w.i = box_hit(mk(w.e01.x, w.e23.x, w.e45.x), mk(w.e01.y, w.e23.y, w.e45.y), cur) ? w.i + 1 : skip;
     } else {
-        float t = 0, u = 0, v = 0;
-        bool ok, wrote = false;
-        if (kind == rt::ENT_SPHERE) ok = sphere_test(mk(w.e01.x, w.e01.y, w.e23.x), w.e23.y, cur, t, wrote);
-        else if (kind == rt::ENT_CUBE) { V3 n; ok = cube_test(mk(w.e01.x, w.e01.y, w.e23.x), mk(w.e23.y, w.e45.x, w.e45.y), cur, t, n); }
-        else ok = tri_test(sc, st.tris, sk_payload(w.sk), w.alpha_img, cur, t, u, v, wrote);
-        if (ok) {
-            if (!w.c.hit || t < w.c.dist) { w.c.hit = true; w.c.dist = t; w.c.best = w.i; w.c.inst = w.inst; w.c.u = u; w.c.v = v; }
-        } else if (wrote && w.i == w.stale) w.c.dist = t;
-        w.i++;
+        // an inner entry tested as the reference writes it, with true divisions: a box with min > max on some axis, or
+        // a ray that is not admitted to the reciprocal path
+        const int skip = kind == rt::ENT_INNER ? (int)w.sk : __float_as_int(reinterpret_cast<const float*>(st.ent)[8 * (size_t)w.i + 7]);
+        w.i = box_hit(mk(w.e01.x, w.e23.x, w.e45.x), mk(w.e01.y, w.e23.y, w.e45.y), walker_ray(w)) ? w.i + 1 : skip;
     }
     walker_load(st, w);
     return done;
 }
-// One round for a wave: box steps while at least `quorum` lanes stand on inner entries (and once more for the
-// stragglers), then a leaf-level action for every lane that stands on something else.  Returns true in lanes whose ray
-// finished.
+// One round for a wave: the traversal loop; then primitive tests, repeated while at least `prim_quorum` lanes have a
+// noted leaf; then the state-changing entries of lanes that have none left.  Returns true in lanes whose ray finished.
+// RT_PROFILE builds (make PROF=1) time the phases of every round with the shader clock; see intersect_kernel
+struct Prof { unsigned long long box = 0, prim = 0, special = 0, refill = 0; unsigned rounds = 0, prims = 0, prim_lanes = 0, specials = 0; };
+#ifdef RT_PROFILE
+#define RT_PROF(x) x
+#else
+#define RT_PROF(x)
+#endif
 template <bool LDS>
-__device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Walker& w, int quorum) {
+__device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Walker& w, int quorum, int prim_quorum, Prof& prof) {
+    RT_PROF(unsigned long long t0 = __builtin_readcyclecounter(); prof.rounds++;)
     box_steps<LDS>(st, w, quorum);
+    RT_PROF(unsigned long long t1 = __builtin_readcyclecounter(); prof.box += t1 - t0;)
+    for (;;) {
+        const bool has = w.cnt != 0;
+        const int n = __popcll(__ballot(has));
+        if (n == 0) break;
+        RT_PROF(prof.prims++; prof.prim_lanes += n;)
+        if (has) prim_step(sc, st, w);
+        if (n < prim_quorum) break;
+    }
+    RT_PROF(unsigned long long t2 = __builtin_readcyclecounter(); prof.prim += t2 - t1;)
+    const int kind = sk_kind(w.sk);
+    const bool special = w.cnt == 0 && (kind == rt::ENT_END || kind == rt::ENT_INSTANCE || kind == rt::ENT_INNER_INV ||
+                                        (kind == rt::ENT_INNER && !w.usable));
     bool done = false;
-    const bool inner = w.sk < (1u << rt::SK_SHIFT) && w.usable;
-    if (!inner && sk_kind(w.sk) != rt::ENT_IDLE) done = walker_leaf(sc, st, w);
+    RT_PROF(if (__any(special)) prof.specials++;)
+    if (special) done = walker_special(sc, st, w);
+    RT_PROF(prof.special += __builtin_readcyclecounter() - t2;)
     return done;
 }
 // Run the lanes of a wave until all of them have finished.
 __device__ __forceinline__ void walk_wave_to_end(const Scene& sc, const Store& st, Walker& w) {
-    while (__any(sk_kind(w.sk) != rt::ENT_IDLE)) walk_round<false>(sc, st, w, 24);
+    Prof prof;
+    while (__any(sk_kind(w.sk) != rt::ENT_IDLE)) walk_round<false>(sc, st, w, 24, 32, prof);
 }
 __device__ __forceinline__ bool walker_is_idle(const Walker& w) { return sk_kind(w.sk) == rt::ENT_IDLE; }
 

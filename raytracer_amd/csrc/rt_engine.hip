@@ -38,16 +38,42 @@ struct Tune {
     int refill_at;   // a wave fetches new rays once this many lanes are idle
     int quorum;      // lanes on inner entries needed to repeat the box-test phase
     int chunk;       // queue positions a wave reserves per atomic (shrunk when a pass holds few rays)
+    int prim_quorum; // lanes with an untested leaf needed to repeat the primitive-test phase
 };
 
+// Division of a 32-bit unsigned number by a divisor fixed for the whole launch: n / d = (((n - q) >> 1) + q) >> shift with
+// q = mulhi(n, magic) — four instructions instead of the ~40 of a hardware-less integer division.  make_fastdiv runs on
+// the host; d = 1 is flagged (the scheme needs d >= 2).
+struct FastDiv { uint32_t magic, shift, d; };
+__host__ inline FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f{0, 0, d};
+    if (d < 2) return f;
+    uint32_t L = 31;
+    while (!((d >> L) & 1u)) L--;                       // floor(log2 d)
+    if ((d & (d - 1)) == 0) { f.magic = 0; f.shift = L - 1; return f; }
+    const unsigned long long two = 1ull << (32 + L);
+    unsigned long long m = two / d;
+    const unsigned long long rem = two % d;
+    m = 2 * m + ((2 * rem >= d) ? 1 : 0);
+    f.magic = (uint32_t)(m + 1);
+    f.shift = L;
+    return f;
+}
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
+    const uint32_t q = __umulhi(n, f.magic);
+    const uint32_t t = (((n - q) >> 1) + q) >> f.shift;
+    return f.d == 1 ? n : t;
+}
+
 struct Cam { V3 pos, fwd, u, v; };
-struct Cfg { int W, H, S, B; float fov, sky, dof, focus; };
+struct Cfg { int W, H, S, B; float fov, sky, dof, focus; FastDiv div_S, div_spp; };
 // which pixels a batch covers: pixels are enumerated tile by tile over the tiles this rank owns
 struct Batch {
     int first_pixel, n_pixels;       // in the rank's pixel enumeration
     int rank, n_ranks, tiles_x, n_tiles, tile_w, tile_h;
     int wx0, wy0, ww, wh;            // render window inside the frame (the whole frame unless a test narrows it)
     uint32_t seed;
+    FastDiv div_per_tile, div_tile_w, div_tiles_x;
 };
 struct Queues {
     float4* a[2]; float4* b[2];      // ray records: a = (o.xyz, d.x), b = (d.y, d.z, slot, ctr | depth << 24)
@@ -58,16 +84,17 @@ struct Queues {
     float4* radiance;                // [slot] = sample radiance
     int capacity;                    // slots
 };
-struct Debug { int32_t* primary_id; float* primary_t; uint32_t* rng_draws; const uint32_t* keys; };
+struct Debug { int32_t* primary_id; float* primary_t; uint32_t* rng_draws; const uint32_t* keys; unsigned long long* prof; };
 
 __device__ __forceinline__ bool pixel_of(const Batch& bt, int lp, int& px, int& py) {
     const int per_tile = bt.tile_w * bt.tile_h;
-    const int t = lp / per_tile, in = lp - t * per_tile;
+    const int t = (int)fdiv((uint32_t)lp, bt.div_per_tile), in = lp - t * per_tile;
     const int tile = bt.rank + t * bt.n_ranks;
     if (tile >= bt.n_tiles) return false;
-    const int ty = tile / bt.tiles_x, tx = tile - ty * bt.tiles_x;
-    py = ty * bt.tile_h + in / bt.tile_w;
-    px = tx * bt.tile_w + in % bt.tile_w;
+    const int ty = (int)fdiv((uint32_t)tile, bt.div_tiles_x), tx = tile - ty * bt.tiles_x;
+    const int row = (int)fdiv((uint32_t)in, bt.div_tile_w);
+    py = ty * bt.tile_h + row;
+    px = tx * bt.tile_w + (in - row * bt.tile_w);
     if (px >= bt.ww || py >= bt.wh) return false;
     px += bt.wx0; py += bt.wy0;
     return true;
@@ -98,12 +125,13 @@ __device__ __forceinline__ bool fetch_ray(const Cam& cam, const Cfg& g, const Ba
     const int spp = g.S * g.S;
     if (FIRST) {
         slot = idx; depth = 0;
-        const int lp = (int)(idx / (uint32_t)spp), s = (int)(idx - (uint32_t)lp * (uint32_t)spp);
+        const int lp = (int)fdiv(idx, g.div_spp), s = (int)(idx - (uint32_t)lp * (uint32_t)spp);
         int px, py;
         if (!pixel_of(bt, bt.first_pixel + lp, px, py)) return false;
         rng.key = sample_key(bt.seed, (uint32_t)(py * g.W + px), (uint32_t)s);
         rng.ctr = 0;
-        ray = camera_ray(cam, g, px, py, s / g.S, s % g.S, rng);
+        const int sx = (int)fdiv((uint32_t)s, g.div_S);
+        ray = camera_ray(cam, g, px, py, sx, s - sx * g.S, rng);
         return true;
     }
     const float4 a = q.a[qin][idx], b = q.b[qin][idx];
@@ -113,7 +141,7 @@ __device__ __forceinline__ bool fetch_ray(const Cam& cam, const Cfg& g, const Ba
     rng.ctr = cd & 0xFFFFFFu; depth = cd >> 24;
     if (dbg.keys) rng.key = dbg.keys[slot];
     else {
-        const int lp = (int)(slot / (uint32_t)spp), s = (int)(slot - (uint32_t)lp * (uint32_t)spp);
+        const int lp = (int)fdiv(slot, g.div_spp), s = (int)(slot - (uint32_t)lp * (uint32_t)spp);
         int px = 0, py = 0;
         pixel_of(bt, bt.first_pixel + lp, px, py);
         rng.key = sample_key(bt.seed, (uint32_t)(py * g.W + px), (uint32_t)s);
@@ -127,12 +155,13 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
     extern __shared__ float4 smem[];
     Store st;
     if (STAGED) {   // whole scene (entries + triangles) into LDS once per block; blocks are persistent
-        const int n_ent4 = 2 * sc.n_entries, n_tri4 = rt::RT_TRI_F4 * sc.n_tris;
+        const int n_ent4 = 2 * sc.n_entries, n_tri4 = rt::RT_TRI_F4 * sc.n_tris, n_inst4 = rt::RT_INST_F4 * sc.n_inst;
         for (int k = threadIdx.x; k < n_ent4; k += blockDim.x) smem[k] = sc.ent[k];
         for (int k = threadIdx.x; k < n_tri4; k += blockDim.x) smem[n_ent4 + k] = sc.tris[k];
+        for (int k = threadIdx.x; k < n_inst4; k += blockDim.x) smem[n_ent4 + n_tri4 + k] = sc.inst[k];
         __syncthreads();
-        st.ent = smem; st.tris = smem + n_ent4;
-    } else { st.ent = sc.ent; st.tris = sc.tris; }
+        st.ent = smem; st.tris = smem + n_ent4; st.inst = smem + n_ent4 + n_tri4;
+    } else { st.ent = sc.ent; st.tris = sc.tris; st.inst = sc.inst; }
     const int qin = (pass + 1) & 1;
     const uint32_t n_in = FIRST ? (uint32_t)bt.n_pixels * (uint32_t)(g.S * g.S) : q.counts[pass];
     uint32_t* cursor = &q.cursors[pass];
@@ -148,7 +177,10 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
     uint32_t chunk = (n_in / (waves * 2u)) & ~63u;
     chunk = chunk < 64u ? 64u : (chunk > (uint32_t)tune.chunk ? (uint32_t)tune.chunk : chunk);
     bool drained = false;   // wave-uniform: every queue position has been handed out
+    Prof prof;
+    RT_PROF(const unsigned long long t_start = __builtin_readcyclecounter(); unsigned n_refills = 0;)
     for (;;) {
+        RT_PROF(const unsigned long long t_r0 = __builtin_readcyclecounter();)
         const unsigned long long idle = __ballot(walker_is_idle(w));
         if (!drained && __popcll(idle) >= tune.refill_at) {
             if (mine == mine_end) {
@@ -170,17 +202,28 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
                 }
                 const uint32_t took = (uint32_t)__popcll(idle);
                 mine = mine + took < mine_end ? mine + took : mine_end;
+                RT_PROF(n_refills++;)
             }
         }
+        RT_PROF(prof.refill += __builtin_readcyclecounter() - t_r0;)
         if (!__any(!walker_is_idle(w))) {
             if (drained) break;
             continue;
         }
-        if (walk_round<STAGED>(sc, st, w, tune.quorum)) {
+        if (walk_round<STAGED>(sc, st, w, tune.quorum, tune.prim_quorum, prof)) {
             q.hit[my_idx] = make_float4(w.c.dist, __int_as_float(w.c.best), w.c.u, w.c.v);
             q.hit_inst[my_idx] = w.c.inst;
         }
     }
+#ifdef RT_PROFILE
+    if (dbg.prof && lane == 0 && prof.rounds) {   // per pass: 12 counters summed over the waves that had work
+        unsigned long long* p = dbg.prof + 12 * (pass < 15 ? pass : 15);
+        atomicAdd(p + 0, 1ull); atomicAdd(p + 1, __builtin_readcyclecounter() - t_start); atomicAdd(p + 2, (unsigned long long)prof.rounds);
+        atomicAdd(p + 3, prof.box); atomicAdd(p + 4, prof.prim); atomicAdd(p + 5, prof.special); atomicAdd(p + 6, prof.refill);
+        atomicAdd(p + 7, (unsigned long long)prof.prims); atomicAdd(p + 8, (unsigned long long)prof.prim_lanes);
+        atomicAdd(p + 9, (unsigned long long)prof.specials); atomicAdd(p + 10, (unsigned long long)n_refills);
+    }
+#endif
 }
 
 // ---- shade + compact (World.cpp:121-170) ------------------------------------------------------------------------------
@@ -309,7 +352,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(Cfg g, Batch bt, const ui
 __global__ __launch_bounds__(256) void trace_kernel(Scene sc, int n, const float* o3, const float* d3, int32_t* hit_id, float* rec9) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     Store st;
-    st.ent = sc.ent; st.tris = sc.tris;
+    st.ent = sc.ent; st.tris = sc.tris; st.inst = sc.inst;
     Walker w;
     walker_idle(sc, w);
     Ray r;
@@ -411,10 +454,10 @@ struct rt_engine {
     Queues q{};
     int n_counts = 0;
     uint8_t* d_frame = nullptr;
-    Debug dbg{nullptr, nullptr, nullptr, nullptr};
+    Debug dbg{nullptr, nullptr, nullptr, nullptr, nullptr};
     bool debug_valid = false;
     int n_cus = 0;
-    Tune tune{16, 24, 256};
+    Tune tune{32, 24, 512, 32};
     int win[4] = {0, 0, 0, 0};          // x0, y0, width, height of the render window
     // statistics of the last render
     std::vector<uint32_t> h_counts;     // per batch: counts (B + 2), cursors (B + 2)
@@ -428,7 +471,10 @@ struct rt_engine {
 
 namespace {
 
-Cfg make_cfg(const rt_config& c) { return Cfg{c.width, c.height, c.samples_per_axis, c.bounces, c.fov, c.skybox_brightness, c.dof_intensity, c.focus_distance}; }
+Cfg make_cfg(const rt_config& c) {
+    return Cfg{c.width, c.height, c.samples_per_axis, c.bounces, c.fov, c.skybox_brightness, c.dof_intensity, c.focus_distance,
+               make_fastdiv((uint32_t)c.samples_per_axis), make_fastdiv((uint32_t)(c.samples_per_axis * c.samples_per_axis))};
+}
 
 void free_scene(rt_engine* e) {
     for (void* p : e->scene_allocs) (void)hipFree(p);
@@ -446,6 +492,8 @@ Batch make_batch(const rt_engine* e, int rank, int n_ranks, uint32_t seed) {
     b.first_pixel = 0; b.n_pixels = 0; b.rank = rank; b.n_ranks = n_ranks;
     b.tiles_x = tiles_x(e); b.n_tiles = tiles_x(e) * tiles_y(e); b.tile_w = c.tile_w; b.tile_h = c.tile_h; b.seed = seed;
     b.wx0 = e->win[0]; b.wy0 = e->win[1]; b.ww = e->win[2]; b.wh = e->win[3];
+    b.div_per_tile = make_fastdiv((uint32_t)(c.tile_w * c.tile_h)); b.div_tile_w = make_fastdiv((uint32_t)c.tile_w);
+    b.div_tiles_x = make_fastdiv((uint32_t)b.tiles_x);
     return b;
 }
 
@@ -539,9 +587,14 @@ int rt_engine_create(const rt_config* cfg, rt_engine** out) {
     HIP_TRY(hipMalloc((void**)&e->d_frame, (size_t)cfg->width * cfg->height * 4));
     HIP_TRY(hipMemset(e->d_frame, 0, (size_t)cfg->width * cfg->height * 4));
     e->n_counts = cfg->bounces + 2;
+#ifdef RT_PROFILE
+    HIP_TRY(hipMalloc((void**)&e->dbg.prof, sizeof(unsigned long long) * 16 * 12));
+    HIP_TRY(hipMemset(e->dbg.prof, 0, sizeof(unsigned long long) * 16 * 12));
+#endif
     if (const char* v = getenv("RT_REFILL_AT")) e->tune.refill_at = std::max(1, std::min(64, atoi(v)));
     if (const char* v = getenv("RT_QUORUM")) e->tune.quorum = std::max(1, std::min(65, atoi(v)));
     if (const char* v = getenv("RT_CHUNK")) e->tune.chunk = std::max(64, atoi(v) & ~63);
+    if (const char* v = getenv("RT_PRIM_QUORUM")) e->tune.prim_quorum = std::max(1, std::min(65, atoi(v)));
     *out = e;
     return RT_OK;
 }
@@ -602,7 +655,14 @@ int rt_engine_set_scene(rt_engine* e, const rt_scene* s) {
     e->scene_allocs.push_back(ent);
     if (int rc = upload(&tris, f->tris.data(), f->tris.size() * 16)) return rc;
     e->scene_allocs.push_back(tris);
-    if (int rc = upload(&inst, f->inst.data(), f->inst.size() * 16)) return rc;
+    // instance records get the image whose alpha channel cuts the mesh out (DataUtility.cpp:123-127), so that entering
+    // an instance needs no look-up in the object table
+    std::vector<rt::F4> inst_rec(f->inst);
+    for (size_t k = 0; k + rt::RT_INST_F4 <= inst_rec.size(); k += rt::RT_INST_F4) {
+        const rt::F4 ob = f->objects[(size_t)rt::bits_i(inst_rec[k + 3].x) * rt::RT_OBJ_F4];
+        inst_rec[k + 3].z = rt::bits_f(rt::bits_i(ob.y) == RT_TEX_IMAGE ? rt::bits_i(ob.z) : -1);
+    }
+    if (int rc = upload(&inst, inst_rec.data(), inst_rec.size() * 16)) return rc;
     e->scene_allocs.push_back(inst);
     if (int rc = upload(&objects, f->objects.data(), f->objects.size() * 16)) return rc;
     e->scene_allocs.push_back(objects);
@@ -616,11 +676,11 @@ int rt_engine_set_scene(rt_engine* e, const rt_scene* s) {
     sc.images = images; sc.texels = texels;
     sc.sky_off = f->sky.offset; sc.sky_w = f->sky.w; sc.sky_h = f->sky.h;
     sc.top_end = f->top_end; sc.stale_entry = f->stale_entry; sc.n_planes = (int)f->planes.size();
-    sc.n_entries = (int)f->ent_lo.size(); sc.n_tris = (int)f->tris.size() / rt::RT_TRI_F4; sc.fast_div_ok = f->fast_div_ok ? 1 : 0;
+    sc.n_entries = (int)f->ent_lo.size(); sc.n_tris = (int)f->tris.size() / rt::RT_TRI_F4; sc.n_inst = (int)f->inst.size() / rt::RT_INST_F4; sc.fast_div_ok = f->fast_div_ok ? 1 : 0;
     sc.idle_entry = f->idle_entry;
     e->sc = sc;
     // stage the whole scene in LDS when two 1024-thread blocks per CU can each hold it (160 KiB per CU)
-    const size_t need = (inter.size() + f->tris.size()) * 16;
+    const size_t need = (inter.size() + f->tris.size() + f->inst.size()) * 16;
     e->staged_bytes = need <= 80 * 1024 ? need : 0;
     if (e->staged_bytes) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->staged_bytes));
@@ -745,7 +805,7 @@ int rt_engine_keep_samples(rt_engine* e, int enable) {
         HIP_TRY(hipMalloc((void**)&e->dbg.rng_draws, cap * 4));
     } else if (!enable && e->dbg.primary_id) {
         (void)hipFree(e->dbg.primary_id); (void)hipFree(e->dbg.primary_t); (void)hipFree(e->dbg.rng_draws);
-        e->dbg = Debug{nullptr, nullptr, nullptr, nullptr};
+        e->dbg = Debug{nullptr, nullptr, nullptr, nullptr, e->dbg.prof};
     }
     e->debug_valid = false;
     return RT_OK;
@@ -831,7 +891,7 @@ int rt_engine_ray_color(rt_engine* e, int n, const float* o3, const float* d3, i
             hipLaunchKernelGGL(load_rays_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, d_o, d_d, e->q.a[1], e->q.b[1], d_counts);
             const Debug saved = e->dbg;
             const bool saved_timing = e->time_kernels;
-            e->dbg = Debug{nullptr, nullptr, nullptr, d_keys};
+            e->dbg = Debug{nullptr, nullptr, nullptr, d_keys, e->dbg.prof};
             e->time_kernels = false;
             Batch bt = make_batch(e, 0, 1, 0);
             bt.n_pixels = 0;
@@ -863,6 +923,21 @@ int rt_engine_get_stats(rt_engine* e, rt_stats* out) {
     HIP_TRY(hipMemcpy(e->h_counts.data(), e->d_counts_all, sizeof(uint32_t) * (size_t)nb * per_batch, hipMemcpyDeviceToHost));
     for (int b = 0; b < nb; b++)
         for (int k = 1; k < nc - 1 && k < 33; k++) out->rays_at_depth[k] += e->h_counts[(size_t)b * per_batch + k];
+#ifdef RT_PROFILE
+    if (e->dbg.prof) {
+        unsigned long long h[16 * 12];
+        HIP_TRY(hipMemcpy(h, e->dbg.prof, sizeof h, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemset(e->dbg.prof, 0, sizeof h));
+        fprintf(stderr, "pass waves cycles/wave rounds/wave box%% prim%% special%% refill%% prim_steps/wave lanes/prim_step specials/wave refills/wave (all renders since the last call)\n");
+        for (int k = 0; k < 16; k++) {
+            const unsigned long long* p = h + 12 * k;
+            if (!p[0]) continue;
+            const double w = (double)p[0], cyc = (double)p[1];
+            fprintf(stderr, "%2d %6llu %9.0f %7.1f %5.1f %5.1f %5.1f %5.1f %7.1f %5.1f %6.1f %6.1f\n", k, p[0], cyc / w, p[2] / w, 100.0 * p[3] / cyc,
+                    100.0 * p[4] / cyc, 100.0 * p[5] / cyc, 100.0 * p[6] / cyc, p[7] / w, p[7] ? (double)p[8] / p[7] : 0.0, p[9] / w, p[10] / w);
+        }
+    }
+#endif
     out->paths = e->last_paths;
     out->rays_at_depth[0] = e->last_paths;
     for (int k = 0; k < 33; k++) out->rays += out->rays_at_depth[k];
