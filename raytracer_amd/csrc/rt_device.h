@@ -309,7 +309,7 @@ __device__ __forceinline__ bool ray_usable(const Ray& r) {
 //   best >= 0: entry index of the winning leaf; best <= -2: plane -(best+2); best == -1: nothing hit.
 //   dist: HitInfo.distance as the reference leaves it — FLT_MAX, the winner's distance, or the stale value the leftmost
 //   leaf assigned before rejecting (Object.cpp:17-19, 534-550), which the plane is then compared against.
-struct Closest { float dist; int best; int inst; float u, v; bool hit; };
+struct Closest { float dist; int best; float u, v; bool hit; };
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int sk_kind(uint32_t sk) { return (int)(sk >> rt::SK_SHIFT); }
@@ -357,13 +357,13 @@ __device__ __forceinline__ void walker_idle(const Scene& sc, Walker& w) {
     w.s0 = w.p0; w.s1 = w.p1; w.s2 = w.p2; w.s3 = w.p3; w.s4 = w.p4; w.s_usable = true;
     w.resume = 0; w.inst = -1; w.stale = -1; w.alpha_img = -1;
     w.f0 = 0; w.f1 = 0; w.f2 = 0; w.cnt = 0;
-    w.c.dist = FLT_MAX; w.c.best = -1; w.c.inst = -1; w.c.u = 0; w.c.v = 0; w.c.hit = false;
+    w.c.dist = FLT_MAX; w.c.best = -1; w.c.u = 0; w.c.v = 0; w.c.hit = false;
 }
 __device__ __forceinline__ void walker_start(const Scene& sc, const Store& st, Walker& w, const Ray& ray) {
     walker_set_ray(w, ray, sc.fast_div_ok != 0);
     w.i = 0; w.resume = 0; w.inst = -1; w.stale = sc.stale_entry; w.alpha_img = -1;
     w.f0 = 0; w.f1 = 0; w.f2 = 0; w.cnt = 0;
-    w.c.dist = FLT_MAX; w.c.best = -1; w.c.inst = -1; w.c.u = 0; w.c.v = 0; w.c.hit = false;
+    w.c.dist = FLT_MAX; w.c.best = -1; w.c.u = 0; w.c.v = 0; w.c.hit = false;
     walker_load(st, w);
 }
 
@@ -587,7 +587,6 @@ __device__ __forceinline__ void prim_step(const Scene& sc, const Store& st, Walk
     const bool stale = !ok && wrote && e == w.stale;
     w.c.dist = (better || stale) ? t : w.c.dist;
     w.c.best = better ? e : w.c.best;
-    w.c.inst = better ? w.inst : w.c.inst;
     w.c.u = better ? u : w.c.u;
     w.c.v = better ? v : w.c.v;
     w.c.hit = w.c.hit || better;
@@ -606,7 +605,7 @@ __device__ __forceinline__ bool walker_special(const Scene& sc, const Store& st,
             for (int p = 0; p < sc.n_planes; p++) {   // YPlane::Intersect (Object.cpp:139-149), merged as World.cpp:110-118
                 const float t = -(top.o.y - sc.planes[p].x) / top.d.y;
                 if (t < 0.001f) continue;             // "t < 1e-3" against a double: the same floats pass
-                if (t < w.c.dist) { w.c.hit = true; w.c.dist = t; w.c.best = -(p + 2); w.c.inst = -1; }
+                if (t < w.c.dist) { w.c.hit = true; w.c.dist = t; w.c.best = -(p + 2); }
             }
             w.i = sc.idle_entry;
             done = true;
@@ -704,7 +703,7 @@ __device__ inline void finalize_hit(const Scene& sc, const Ray& ray, const Close
         else if (n.y == 1 || n.y == -1) { h.u = m01.x; h.v = m01.z; }
         else { h.u = m01.x; h.v = m01.y; }
     } else {   // triangle inside a mesh instance
-        const float4* I = sc.inst + (size_t)c.inst * rt::RT_INST_F4;
+        const float4* I = sc.inst + (size_t)__float_as_int(eb.w) * rt::RT_INST_F4;
         const float4 i0 = I[0], i1 = I[1], i2 = I[2], i3 = I[3];
         const Ray q = to_instance(i0, i1, i2, ray);
         const float4* T = sc.tris + (size_t)sk_payload(sk) * rt::RT_TRI_F4;

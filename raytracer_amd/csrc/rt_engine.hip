@@ -10,8 +10,9 @@
 //               finished paths unwind their colour stack and store the sample's radiance.
 //   resolve   : per pixel, sum the samples in the reference's order, tone-map, pack [A,B,G,R] (World.cpp:94-100).
 //
-// A path owns a slot in the batch; its RNG stream is keyed by (frame seed, pixel, sample), so the result of a slot does
-// not depend on scheduling.  The recursion of World::GetRayColor multiplies colours on the way back (innermost first);
+// A path owns a slot in the batch, slot = pixel * spp + sample: the 64 lanes of a wave start on the samples of one pixel,
+// as coherent as primary rays get (enumerating the paths sample-major instead costs the first intersect pass 20 %).
+// Its RNG stream is keyed by (frame seed, pixel, sample), so the result of a slot does not depend on scheduling.  The recursion of World::GetRayColor multiplies colours on the way back (innermost first);
 // to reproduce that rounding order every bounce stores its (factor, texture colour) in a per-slot stack which the
 // terminating pass unwinds.
 #include <hip/hip_runtime.h>
@@ -77,7 +78,7 @@ struct Batch {
 };
 struct Queues {
     float4* a[2]; float4* b[2];      // ray records: a = (o.xyz, d.x), b = (d.y, d.z, slot, ctr | depth << 24)
-    float4* hit; int* hit_inst;      // hit records by queue position: (distance, best entry, u, v), instance
+    float4* hit;                     // hit records by queue position: (distance, best entry, u, v)
     uint32_t* counts;                // counts[k] = rays entering pass k
     uint32_t* cursors;               // cursors[k] = queue positions of pass k handed out to intersect waves so far
     float4* stack;                   // [depth][slot] = (texture colour rgb, factor)
@@ -212,7 +213,6 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
         }
         if (walk_round<STAGED>(sc, st, w, tune.quorum, tune.prim_quorum, prof)) {
             q.hit[my_idx] = make_float4(w.c.dist, __int_as_float(w.c.best), w.c.u, w.c.v);
-            q.hit_inst[my_idx] = w.c.inst;
         }
     }
 #ifdef RT_PROFILE
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void shade_kernel(Scene sc, Cam cam, Cfg g, Ba
         if (live) {
             const float4 hr = q.hit[i];
             Closest c;
-            c.dist = hr.x; c.best = __float_as_int(hr.y); c.u = hr.z; c.v = hr.w; c.inst = q.hit_inst[i]; c.hit = c.best != -1;
+            c.dist = hr.x; c.best = __float_as_int(hr.y); c.u = hr.z; c.v = hr.w; c.hit = c.best != -1;
             Hit h;
             if (c.hit) finalize_hit(sc, ray, c, h);
             if (FIRST) {
@@ -318,17 +318,34 @@ __global__ __launch_bounds__(256) void shade_kernel(Scene sc, Cam cam, Cfg g, Ba
 }
 
 // ---- resolve: World.cpp:94-100 + FrameManager.cpp:89-94.  (char)(c * 255): truncation, then the low byte ---------------
+// The samples of a pixel are summed one after another in sample order, as the reference does (float addition does not
+// associate), so a pixel is one thread's work; but a thread reading its pixel's spp consecutive records would make every
+// wave access 64 distant addresses per load.  A block therefore copies the records of RPB pixels (RCH samples at a time)
+// into LDS with consecutive lanes on consecutive records, and the pixel threads add them up from there.
+constexpr int RTILE = 2048;   // float4 records staged per block and step (32 KiB)
 __device__ __forceinline__ uint32_t to_u8(float c) { return (uint32_t)(int)(c * 255) & 0xFFu; }
-__global__ __launch_bounds__(256) void resolve_kernel(Cfg g, Batch bt, const float4* radiance, uint8_t* out, int packed) {
-    const int lp = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lp >= bt.n_pixels) return;
+__global__ __launch_bounds__(256) void resolve_kernel(Cfg g, Batch bt, const float4* radiance, uint8_t* out, int packed, int rpb, int rch, FastDiv div_rch) {
+    __shared__ float4 tile[RTILE + 256];
+    const int spp = g.S * g.S;
+    const int p0 = blockIdx.x * rpb;                                   // first pixel of the block
+    const int n_p = min(rpb, bt.n_pixels - p0);
+    V3 color = mk(0, 0, 0);
+    for (int s0 = 0; s0 < spp; s0 += rch) {
+        const int n_s = min(rch, spp - s0);
+        for (int k = threadIdx.x; k < n_p * rch; k += 256) {
+            const int p = (int)fdiv((uint32_t)k, div_rch), j = k - p * rch;
+            if (j < n_s) tile[p * (rch + 1) + j] = radiance[(size_t)(p0 + p) * spp + s0 + j];
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < n_p)
+            for (int j = 0; j < n_s; j++) { const float4 v = tile[threadIdx.x * (rch + 1) + j]; color = color + mk(v.x, v.y, v.z); }
+        __syncthreads();
+    }
+    if ((int)threadIdx.x >= n_p) return;
+    const int lp = p0 + threadIdx.x;
     int px, py;
     const int glp = bt.first_pixel + lp;
     if (!pixel_of(bt, glp, px, py)) return;
-    const int spp = g.S * g.S;
-    V3 color = mk(0, 0, 0);
-    const float4* r = radiance + (size_t)lp * spp;
-    for (int s = 0; s < spp; s++) { const float4 v = r[s]; color = color + mk(v.x, v.y, v.z); }
     color = divs(color, (float)spp);
     const float steepness = 5.0f;
     color = mk(1.0f - 1.0f / (1.0f + steepness * color.x), 1.0f - 1.0f / (1.0f + steepness * color.y), 1.0f - 1.0f / (1.0f + steepness * color.z));
@@ -581,7 +598,6 @@ int rt_engine_create(const rt_config* cfg, rt_engine** out) {
         HIP_TRY(hipMalloc((void**)&e->q.b[k], cap * sizeof(float4)));
     }
     HIP_TRY(hipMalloc((void**)&e->q.hit, cap * sizeof(float4)));
-    HIP_TRY(hipMalloc((void**)&e->q.hit_inst, cap * sizeof(int)));
     HIP_TRY(hipMalloc((void**)&e->q.stack, cap * sizeof(float4) * (size_t)std::max(1, cfg->bounces)));
     HIP_TRY(hipMalloc((void**)&e->q.radiance, cap * sizeof(float4)));
     HIP_TRY(hipMalloc((void**)&e->d_frame, (size_t)cfg->width * cfg->height * 4));
@@ -605,7 +621,7 @@ void rt_engine_destroy(rt_engine* e) {
     (void)hipStreamSynchronize(e->stream);
     free_scene(e);
     for (int k = 0; k < 2; k++) { (void)hipFree(e->q.a[k]); (void)hipFree(e->q.b[k]); }
-    (void)hipFree(e->q.hit); (void)hipFree(e->q.hit_inst);
+    (void)hipFree(e->q.hit);
     (void)hipFree(e->q.stack); (void)hipFree(e->q.radiance); (void)hipFree(e->d_frame); (void)hipFree(e->d_counts_all);
     (void)hipFree(e->dbg.primary_id); (void)hipFree(e->dbg.primary_t); (void)hipFree(e->dbg.rng_draws);
     for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
@@ -651,6 +667,10 @@ int rt_engine_set_scene(rt_engine* e, const rt_scene* s) {
         }
         inter[2 * i] = a; inter[2 * i + 1] = b;
     }
+    // a triangle entry names the instance it belongs to (every instance has its own range of entries)
+    for (size_t k = 0; k + rt::RT_INST_F4 <= f->inst.size(); k += rt::RT_INST_F4)
+        for (int i = rt::bits_i(f->inst[k + 2].z); i < rt::bits_i(f->inst[k + 2].w); i++)
+            if (rt::bits_i(f->ent_hi[i].w) == rt::ENT_TRI) inter[2 * (size_t)i + 1].w = rt::bits_f((int)(k / rt::RT_INST_F4));
     if (int rc = upload(&ent, inter.data(), inter.size() * 16)) return rc;
     e->scene_allocs.push_back(ent);
     if (int rc = upload(&tris, f->tris.data(), f->tris.size() * 16)) return rc;
@@ -750,7 +770,12 @@ int rt_engine_render(rt_engine* e, uint32_t seed, int rank, int n_ranks, uint8_t
         bt.n_pixels = (int)std::min<long long>(batch_pixels, my_pixels - (long long)b * batch_pixels);
         uint32_t* counts = e->d_counts_all + (size_t)b * per_batch;
         if (int rc = run_passes(e, bt, st, counts, false, c.bounces)) return rc;
-        hipLaunchKernelGGL(resolve_kernel, dim3((bt.n_pixels + 255) / 256), dim3(256), 0, st, g, bt, e->q.radiance, out, n_ranks > 1 ? 1 : 0);
+        {   // pixels per block and samples per step so that a step's records fill the staging tile (padded rows of rch + 1)
+            const int rpb = std::max(1, std::min(256, RTILE / (spp + 1)));
+            const int rch = std::min(spp, RTILE / rpb - 1);
+            hipLaunchKernelGGL(resolve_kernel, dim3((bt.n_pixels + rpb - 1) / rpb), dim3(256), 0, st, g, bt, e->q.radiance, out, n_ranks > 1 ? 1 : 0,
+                               rpb, rch, make_fastdiv((uint32_t)rch));
+        }
     }
     HIP_TRY(hipGetLastError());
     return RT_OK;

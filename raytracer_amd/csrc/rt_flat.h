@@ -24,7 +24,8 @@
 //                                                 Object.cpp:29-35,156-166): tested by the general slab test
 //   SPHERE     c.x c.y c.z radius 0 0 | kind, object id | 0
 //   CUBE       min.xyz max.xyz | kind, object id | 0
-//   TRI        0 0 0 0 0 0 | kind, triangle index | 0          INSTANCE  likewise with the instance index
+//   TRI        0 0 0 0 0 0 | kind, triangle index | instance the triangle belongs to
+//   INSTANCE   0 0 0 0 0 0 | kind, instance index | 0
 //   END, IDLE  0 ... | kind | 0
 //
 // Triangle (RT_TRI_F4 = 6 records):  (v0.xyz, -) (v1.xyz, -) (v2.xyz, -) (uv0.xy, uv1.xy) (uv2.xy, n.x, n.y) (n.z, -, -, -)
