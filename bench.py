@@ -39,14 +39,14 @@ FLOP_SHADE = {"sph_hit": 25, "cube_hit": 21, "plane_hit": 6, "inst_hit": 21, "sh
 # cube, 36 B per triangle (+40 B on the uv path).  The engine serves them from its LDS copy of the scene when it fits.
 SCENE_BYTE_WEIGHTS = {"aabb": 32, "sph_test": 16, "cube_test": 24, "tri_test": 36, "tri_uv": 40}
 # bytes intersect_kernel streams through HBM per ray: 32 B ray record read (bounce rays; primary rays are generated in
-# registers) and 20 B hit record written
-RAY_READ_BYTES, HIT_WRITE_BYTES = 32, 20
+# registers) and 16 B hit record written
+RAY_READ_BYTES, HIT_WRITE_BYTES = 32, 16
 PEAK_FP32_TFLOPS = 157.3     # MI355X vector FP32 with packed FMA; unfused scalar-per-lane code can reach 1/4 of it
 PEAK_HBM_GBS = 8000.0
 # per-ray figures of the reference algorithm measured by the oracle's event counters over the CPU sample of each workload;
 # used when the CPU leg is skipped (--no-cpu-baseline, N > 1)
-FALLBACK_FLOP_PER_RAY = {"c1": 985.0, "c2": 985.0, "c3": 1500.0}
-FALLBACK_SCENE_BYTE_PER_RAY = {"c1": 1480.0, "c2": 1480.0, "c3": 2500.0}
+FALLBACK_FLOP_PER_RAY = {"c1": 1002.0, "c2": 1002.0, "c3": 7000.0}
+FALLBACK_SCENE_BYTE_PER_RAY = {"c1": 1480.0, "c2": 1480.0, "c3": 13400.0}
 
 
 def build_scene(rt, workload):

@@ -2,9 +2,11 @@
 //
 // One batch of paths (a path = one pixel sample) is advanced bounce by bounce; every pass is two kernels over a ray queue:
 //
-//   intersect : persistent waves pull rays from the queue (pass 0: generate them from the camera, World.cpp:68-88), walk
-//               the stackless two-level BVH with the scene staged in LDS, and refill finished lanes with new rays, so a
-//               long traversal does not idle the other 63 lanes.  Writes one 20-byte hit record per ray.
+//   intersect : persistent waves pull rays from the queue (pass 0: generate them from the camera, World.cpp:68-88) and
+//               walk the stackless two-level BVH with the scene staged in LDS.  Lanes do not stop at leaves: they note
+//               them and walk on; primitive tests run in batches; finished lanes are refilled with new rays, so a
+//               long traversal does not idle the other 63 lanes (rt_device.h: box_steps, prim_step, walk_round).
+//               Writes one 16-byte hit record per ray.
 //   shade     : one lane per ray: finish the hit (point, normal, uv), material switch, texture lookup, bounce sampling
 //               (World.cpp:121-170); survivors are compacted into the other queue with a wave64 ballot + prefix count;
 //               finished paths unwind their colour stack and store the sample's radiance.
@@ -474,7 +476,7 @@ struct rt_engine {
     Debug dbg{nullptr, nullptr, nullptr, nullptr, nullptr};
     bool debug_valid = false;
     int n_cus = 0;
-    Tune tune{32, 24, 512, 32};
+    Tune tune{32, 8, 512, 16};
     int win[4] = {0, 0, 0, 0};          // x0, y0, width, height of the render window
     // statistics of the last render
     std::vector<uint32_t> h_counts;     // per batch: counts (B + 2), cursors (B + 2)
