@@ -127,6 +127,7 @@ struct Scene {
     const float4* ent;   // 2 x float4 per entry: lo, hi
     const float4* tris; const float4* inst; const float4* objects; const float4* planes;
     const rt::ImageRec* images; const uint8_t* texels;
+    const uint32_t* alpha_bits;   // one bit per texel of every image: alpha >= 1
     uint32_t sky_off, sky_w, sky_h;
     int top_end, stale_entry, n_planes;
     int n_entries, n_tris, n_inst, fast_div_ok, idle_entry;
@@ -201,9 +202,12 @@ __device__ __forceinline__ int image_index(const rt::ImageRec im, float u, float
     const uint32_t row = (uint32_t)(int)(v * (float)im.h), col = (uint32_t)(int)(u * (float)im.w);
     return 4 * (int)(row * im.w + col);
 }
-// Triangle::Intersect (Object.cpp:498-550).  alpha_img >= 0: the material's image texture decides solidity
-// (DataUtility.cpp:123-127).  `wrote`: HitInfo.distance was assigned although the triangle was rejected by the cut-out.
-__device__ __forceinline__ bool tri_test(const Scene& sc, const float4* tris, int ti, int alpha_img, const Ray& r, float& t, float& uo, float& vo, bool& wrote) {
+// Triangle::Intersect (Object.cpp:498-550).  alpha_off >= 0: the material's image texture decides solidity
+// (DataUtility.cpp:123-127: alpha byte > 0.01f, i.e. alpha >= 1) — looked up in a one-bit-per-texel copy of the alpha
+// channel at word alpha_off of Scene::alpha_bits (alpha_wh = height << 16 | width), 32 times smaller than the texels and
+// therefore resident in the vector cache.  `wrote`: HitInfo.distance was assigned although the triangle was rejected
+// by the cut-out.
+__device__ __forceinline__ bool tri_test(const Scene& sc, const float4* tris, int ti, int alpha_off, uint32_t alpha_wh, const Ray& r, float& t, float& uo, float& vo, bool& wrote) {
     const float EPSILON = 0.0000001f;
     const float4* T = tris + (size_t)ti * rt::RT_TRI_F4;
     const V3 v0 = xyz(T[0]), v1 = xyz(T[1]), v2 = xyz(T[2]);
@@ -238,10 +242,10 @@ __device__ __forceinline__ bool tri_test(const Scene& sc, const float4* tris, in
     if (uu < 0) uu += 1;
     if (vv < 0) vv += 1;
     uo = uu; vo = vv;
-    if (alpha_img >= 0) {
-        const rt::ImageRec im = sc.images[alpha_img];
-        const uint8_t alpha = sc.texels[im.offset + (uint32_t)(image_index(im, uu, vv) + 3)];
-        if (!((float)alpha > 0.01f)) return false;
+    if (alpha_off >= 0) {
+        const uint32_t w = alpha_wh & 0xFFFFu, h = alpha_wh >> 16;
+        const uint32_t texel = (uint32_t)(int)(vv * (float)h) * w + (uint32_t)(int)(uu * (float)w);   // DataUtility.h:82
+        if (!((sc.alpha_bits[(uint32_t)alpha_off + (texel >> 5)] >> (texel & 31u)) & 1u)) return false;
     }
     return true;
 }
@@ -326,7 +330,8 @@ struct Walker {
     // while inside an instance: the same for the ray as given, to come back to
     f2 s0, s1, s2, s3, s4;
     bool s_usable;
-    int i, resume, inst, stale, alpha_img;
+    int i, resume, inst, stale, alpha_off;
+    uint32_t alpha_wh;
     f2 e01, e23, e45;        // dwords 0..5 of the entry
     uint32_t sk;             // dword 6: kind << 28 | payload; for an inner entry (kind 0) simply the skip index
     uint32_t f0, f1, f2, cnt;   // leaves visited but not yet tested, oldest first, and their number (0..3)
@@ -355,13 +360,13 @@ __device__ __forceinline__ void walker_idle(const Scene& sc, Walker& w) {
     w.e01 = f2{0, 0}; w.e23 = f2{0, 0}; w.e45 = f2{0, 0};
     w.p0 = f2{0, 0}; w.p1 = f2{0, 1}; w.p2 = f2{1, 1}; w.p3 = f2{1, 1}; w.p4 = f2{1, 0}; w.usable = true;
     w.s0 = w.p0; w.s1 = w.p1; w.s2 = w.p2; w.s3 = w.p3; w.s4 = w.p4; w.s_usable = true;
-    w.resume = 0; w.inst = -1; w.stale = -1; w.alpha_img = -1;
+    w.resume = 0; w.inst = -1; w.stale = -1; w.alpha_off = -1; w.alpha_wh = 0;
     w.f0 = 0; w.f1 = 0; w.f2 = 0; w.cnt = 0;
     w.c.dist = FLT_MAX; w.c.best = -1; w.c.u = 0; w.c.v = 0; w.c.hit = false;
 }
 __device__ __forceinline__ void walker_start(const Scene& sc, const Store& st, Walker& w, const Ray& ray) {
     walker_set_ray(w, ray, sc.fast_div_ok != 0);
-    w.i = 0; w.resume = 0; w.inst = -1; w.stale = sc.stale_entry; w.alpha_img = -1;
+    w.i = 0; w.resume = 0; w.inst = -1; w.stale = sc.stale_entry; w.alpha_off = -1; w.alpha_wh = 0;
     w.f0 = 0; w.f1 = 0; w.f2 = 0; w.cnt = 0;
     w.c.dist = FLT_MAX; w.c.best = -1; w.c.u = 0; w.c.v = 0; w.c.hit = false;
     walker_load(st, w);
@@ -576,7 +581,7 @@ __device__ __forceinline__ void prim_step(const Scene& sc, const Store& st, Walk
     const Ray cur = walker_ray(w);
     float t = 0, u = 0, v = 0;
     bool ok, wrote = false;
-    if (kind == rt::ENT_TRI) ok = tri_test(sc, st.tris, sk_payload(sk), w.alpha_img, cur, t, u, v, wrote);
+    if (kind == rt::ENT_TRI) ok = tri_test(sc, st.tris, sk_payload(sk), w.alpha_off, w.alpha_wh, cur, t, u, v, wrote);
     else {
         const f2 a = E[0], b = E[1], c = E[2];
         if (kind == rt::ENT_SPHERE) ok = sphere_test(mk(a.x, a.y, b.x), b.y, cur, t, wrote);
@@ -619,7 +624,7 @@ __device__ __forceinline__ bool walker_special(const Scene& sc, const Store& st,
         w.resume = w.i + 1;
         w.stale = (w.i == sc.stale_entry) ? __float_as_int(i3.y) : -1;
         w.inst = ii;
-        w.alpha_img = __float_as_int(i3.z);   // image whose alpha channel cuts the mesh out, or -1
+        w.alpha_off = __float_as_int(i3.z); w.alpha_wh = __float_as_uint(i3.w);   // alpha cut-out of the mesh's texture, or -1
         w.i = __float_as_int(i2.z);
     } else {
         // an inner entry tested as the reference writes it, with true divisions: a box with min > max on some axis, or

@@ -677,13 +677,41 @@ int rt_engine_set_scene(rt_engine* e, const rt_scene* s) {
     e->scene_allocs.push_back(ent);
     if (int rc = upload(&tris, f->tris.data(), f->tris.size() * 16)) return rc;
     e->scene_allocs.push_back(tris);
-    // instance records get the image whose alpha channel cuts the mesh out (DataUtility.cpp:123-127), so that entering
-    // an instance needs no look-up in the object table
+    // one bit per texel of every image: "alpha byte > 0.01f" (DataUtility.cpp:123-127).  The padding row of the texel
+    // pool (all zero) is covered too, because uv == 1 indexes one row past the image.
+    std::vector<uint32_t> alpha_bits;
+    std::vector<int> alpha_at(f->images.size(), -1);
+    for (size_t k = 0; k < f->images.size(); k++) {
+        const rt::ImageRec& im = f->images[k];
+        if (im.channels != 4 || im.w > 0xFFFFu || im.h > 0xFFFFu) continue;
+        alpha_at[k] = (int)alpha_bits.size();
+        const size_t texels = (size_t)im.w * (im.h + 1) + 32;
+        alpha_bits.resize(alpha_bits.size() + (texels + 31) / 32, 0u);
+        for (size_t t = 0; t < (size_t)im.w * (im.h + 1); t++) {
+            const size_t byte = (size_t)im.offset + 4 * t + 3;
+            if (byte < f->texels.size() && f->texels[byte] >= 1) alpha_bits[(size_t)alpha_at[k] + (t >> 5)] |= 1u << (t & 31);
+        }
+    }
+    // instance records get the alpha mask of the mesh's image texture, so that entering an instance needs no look-up
+    // in the object table
     std::vector<rt::F4> inst_rec(f->inst);
     for (size_t k = 0; k + rt::RT_INST_F4 <= inst_rec.size(); k += rt::RT_INST_F4) {
         const rt::F4 ob = f->objects[(size_t)rt::bits_i(inst_rec[k + 3].x) * rt::RT_OBJ_F4];
-        inst_rec[k + 3].z = rt::bits_f(rt::bits_i(ob.y) == RT_TEX_IMAGE ? rt::bits_i(ob.z) : -1);
+        int at = -1;
+        uint32_t wh = 0;
+        if (rt::bits_i(ob.y) == RT_TEX_IMAGE) {
+            const int img = rt::bits_i(ob.z);
+            if (alpha_at[img] < 0) return fail(RT_E_INVALID, "image textures must be RGBA and at most 65535 texels wide and high");
+            at = alpha_at[img];
+            wh = (f->images[img].h << 16) | f->images[img].w;
+        }
+        inst_rec[k + 3].z = rt::bits_f(at);
+        inst_rec[k + 3].w = rt::bits_f((int32_t)wh);
     }
+    uint32_t* d_alpha;
+    if (int rc = upload(&d_alpha, alpha_bits.data(), alpha_bits.size() * 4)) return rc;
+    e->scene_allocs.push_back(d_alpha);
+    sc.alpha_bits = d_alpha;
     if (int rc = upload(&inst, inst_rec.data(), inst_rec.size() * 16)) return rc;
     e->scene_allocs.push_back(inst);
     if (int rc = upload(&objects, f->objects.data(), f->objects.size() * 16)) return rc;
