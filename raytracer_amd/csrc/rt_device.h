@@ -385,7 +385,7 @@ __device__ __forceinline__ void walker_start(const Scene& sc, const Store& st, W
 // It repeats while at least `quorum` lanes stand on inner entries (and runs once more for the stragglers).  Lanes on
 // anything else (END, INSTANCE, boxes or rays that need the general test, a full FIFO) wait for the caller.
 //
-// This is the instruction stream the renderer spends most of its time in, so it is written out by hand: 33 vector
+// This is the instruction stream the renderer spends most of its time in, so it is written out by hand: 25 vector
 // instructions per box step where the compiler's schedule of the same arithmetic needs 50 to 70 (it keeps the entry in
 // four-register tuples, rebuilds operand pairs and copies loop-carried values around the loop).
 //   * the entry holds the bounds of an axis side by side (min.x, max.x) (min.y, max.y) (min.z, max.z): one packed
@@ -398,6 +398,11 @@ __device__ __forceinline__ void walker_start(const Scene& sc, const Store& st, W
 //     axis's own entry never exceeds its own exit for such a box, so "not rejected" is max3(entries) <= min3(exits), and
 //     the last test, both distances negative (:78), is then "exit < 0".  Entry/exit per axis are picked by the sign of
 //     the direction (px, py, pz: lane masks of d >= 0), as the reference does;
+//   * the decision is first made on one-multiplication quotients (c - o) * (1/d), each within 1.5 * 2^-23 of the true
+//     quotient's rounding; when the largest entry and the smallest exit distance are further apart than 2^-20 of their
+//     magnitude the exactly rounded quotients order the same way (and a quotient's sign is that of its product), so the
+//     decision stands.  Only if some lane is closer than that does the wave compute the exact quotients (the four packed
+//     FMAs per axis) and decide again — a few box tests in a million;
 //   * the loads land in the registers that already hold the entry (tied operands): nothing is copied;
 //   * the lanes that act are enabled through exec inside the block (restored before every test and at the end), so the
 //     surrounding control flow is wave-uniform.
@@ -432,6 +437,27 @@ __device__ __forceinline__ void box_steps(const Store& st, Walker& w, int quorum
                  "v_pk_mul_f32 v[2:3], v[10:11], %16 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
                  "v_pk_mul_f32 v[4:5], v[12:13], %17 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
                  "v_pk_mul_f32 v[6:7], v[14:15], %17 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                 "v_cndmask_b32_e64 v8, v3, v2, %20\n\t"
+                 "v_cndmask_b32_e64 v3, v2, v3, %20\n\t"
+                 "v_cndmask_b32_e64 v2, v5, v4, %21\n\t"
+                 "v_cndmask_b32_e64 v5, v4, v5, %21\n\t"
+                 "v_cndmask_b32_e64 v4, v7, v6, %22\n\t"
+                 "v_cndmask_b32_e64 v7, v6, v7, %22\n\t"
+                 "v_max3_f32 v8, v8, v2, v4\n\t"
+                 "v_min3_f32 v3, v3, v5, v7\n\t"
+                 "v_cmp_le_f32_e32 vcc, v8, v3\n\t"
+                 "v_cmp_nlt_f32_e64 %11, v3, 0\n\t"
+                 "v_sub_f32_e32 v9, v3, v8\n\t"
+                 "v_max_f32_e64 v2, |v8|, |v3|\n\t"
+                 "s_and_b64 vcc, vcc, %11\n\t"
+                 "v_mul_f32_e32 v2, 0x35800000, v2\n\t"
+                 "v_add_u32_e32 v4, 1, %4\n\t"
+                 "v_cmp_le_f32_e64 %11, |v9|, v2\n\t"
+                 "s_cmp_eq_u64 %11, 0\n\t"
+                 "s_cbranch_scc1 5f\n\t"
+                 "v_pk_mul_f32 v[2:3], v[10:11], %16 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                 "v_pk_mul_f32 v[4:5], v[12:13], %17 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+                 "v_pk_mul_f32 v[6:7], v[14:15], %17 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
                  "v_pk_fma_f32 v[16:17], %18, v[2:3], v[10:11] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
                  "v_pk_fma_f32 v[18:19], %18, v[4:5], v[12:13] op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
                  "v_pk_fma_f32 v[20:21], %19, v[6:7], v[14:15] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
@@ -454,10 +480,11 @@ __device__ __forceinline__ void box_steps(const Store& st, Walker& w, int quorum
                  "v_min3_f32 v3, v3, v5, v7\n\t"
                  "v_cmp_le_f32_e32 vcc, v8, v3\n\t"
                  "v_cmp_nlt_f32_e64 %11, v3, 0\n\t"
-                 "v_add_u32_e32 v2, 1, %4\n\t"
+                 "v_add_u32_e32 v4, 1, %4\n\t"
                  "s_and_b64 vcc, vcc, %11\n\t"
+                 "5:\n\t"
                  "s_nop 0\n\t"
-                 "v_cndmask_b32_e32 %4, %3, v2, vcc\n\t"
+                 "v_cndmask_b32_e32 %4, %3, v4, vcc\n\t"
                  "3:\n\t"
                  "s_cmp_eq_u64 %10, 0\n\t"
                  "s_cbranch_scc1 4f\n\t"
@@ -511,6 +538,27 @@ __device__ __forceinline__ void box_steps(const Store& st, Walker& w, int quorum
                  "v_pk_mul_f32 v[2:3], v[10:11], %16 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
                  "v_pk_mul_f32 v[4:5], v[12:13], %17 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
                  "v_pk_mul_f32 v[6:7], v[14:15], %17 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                 "v_cndmask_b32_e64 v8, v3, v2, %20\n\t"
+                 "v_cndmask_b32_e64 v3, v2, v3, %20\n\t"
+                 "v_cndmask_b32_e64 v2, v5, v4, %21\n\t"
+                 "v_cndmask_b32_e64 v5, v4, v5, %21\n\t"
+                 "v_cndmask_b32_e64 v4, v7, v6, %22\n\t"
+                 "v_cndmask_b32_e64 v7, v6, v7, %22\n\t"
+                 "v_max3_f32 v8, v8, v2, v4\n\t"
+                 "v_min3_f32 v3, v3, v5, v7\n\t"
+                 "v_cmp_le_f32_e32 vcc, v8, v3\n\t"
+                 "v_cmp_nlt_f32_e64 %11, v3, 0\n\t"
+                 "v_sub_f32_e32 v9, v3, v8\n\t"
+                 "v_max_f32_e64 v2, |v8|, |v3|\n\t"
+                 "s_and_b64 vcc, vcc, %11\n\t"
+                 "v_mul_f32_e32 v2, 0x35800000, v2\n\t"
+                 "v_add_u32_e32 v4, 1, %4\n\t"
+                 "v_cmp_le_f32_e64 %11, |v9|, v2\n\t"
+                 "s_cmp_eq_u64 %11, 0\n\t"
+                 "s_cbranch_scc1 5f\n\t"
+                 "v_pk_mul_f32 v[2:3], v[10:11], %16 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                 "v_pk_mul_f32 v[4:5], v[12:13], %17 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+                 "v_pk_mul_f32 v[6:7], v[14:15], %17 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
                  "v_pk_fma_f32 v[16:17], %18, v[2:3], v[10:11] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
                  "v_pk_fma_f32 v[18:19], %18, v[4:5], v[12:13] op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
                  "v_pk_fma_f32 v[20:21], %19, v[6:7], v[14:15] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
@@ -533,10 +581,11 @@ __device__ __forceinline__ void box_steps(const Store& st, Walker& w, int quorum
                  "v_min3_f32 v3, v3, v5, v7\n\t"
                  "v_cmp_le_f32_e32 vcc, v8, v3\n\t"
                  "v_cmp_nlt_f32_e64 %11, v3, 0\n\t"
-                 "v_add_u32_e32 v2, 1, %4\n\t"
+                 "v_add_u32_e32 v4, 1, %4\n\t"
                  "s_and_b64 vcc, vcc, %11\n\t"
+                 "5:\n\t"
                  "s_nop 0\n\t"
-                 "v_cndmask_b32_e32 %4, %3, v2, vcc\n\t"
+                 "v_cndmask_b32_e32 %4, %3, v4, vcc\n\t"
                  "3:\n\t"
                  "s_cmp_eq_u64 %10, 0\n\t"
                  "s_cbranch_scc1 4f\n\t"
