@@ -366,3 +366,50 @@ def test_front_end_adapter_matches_the_c_abi(rt, gpu_default, tmp_path):
     e.set_camera(rt.camera_look(CAM_POS, CAM_LOOK))
     assert_bits(raw.reshape(H, W, 4), e.render_frame(2), "adapter frame vs C ABI frame")   # first frame: frameSeed 2
     assert e.poll() is True
+
+
+def _grazing_rays(boxes, n_origins, seed):
+    """rays aimed at the corners and edge midpoints of the given boxes (float rounding puts them a hair inside or
+    outside): the cases where a slab test's entry and exit distances nearly coincide"""
+    rng = np.random.default_rng(seed)
+    lo, hi = boxes[:, :3].astype(np.float64), boxes[:, 3:].astype(np.float64)
+    pts = []
+    for cx in (0.0, 0.5, 1.0):
+        for cy in (0.0, 0.5, 1.0):
+            for cz in (0.0, 0.5, 1.0):
+                if (cx == 0.5) + (cy == 0.5) + (cz == 0.5) <= 1:          # corners and edge midpoints
+                    pts.append(lo + (hi - lo) * np.array([cx, cy, cz]))
+    pts = np.concatenate(pts)
+    pts = pts[np.isfinite(pts).all(axis=1)]
+    o = rng.uniform(-60.0, 60.0, (n_origins, 1, 3)) * np.array([1.0, 0.4, 1.0]) + np.array([0.0, 25.0, 0.0])
+    d = pts[None, :, :] - o
+    d /= np.linalg.norm(d, axis=2, keepdims=True)
+    o = np.broadcast_to(o, d.shape)
+    return o.reshape(-1, 3).astype(np.float32), d.reshape(-1, 3).astype(np.float32)
+
+
+def test_grazing_rays_decide_like_the_oracle(rt, orc, golden, assets, oracle_default, gpu_default):
+    """The box step decides on approximate quotients and falls back to exactly rounded ones when the decision is close;
+    rays through box corners and along box edges are where that matters.  Both variants of the traversal loop: scene in
+    LDS (ray_color on the default scene) and scene in global memory (trace; the 3000-primitive scene)."""
+    e = make_engine(rt, gpu_default, 256, 256, 2, 3)    # ray_color needs queue room for every ray and 3 bounce levels
+    o, d = _grazing_rays(gpu_default.dump_top()[0], 40, 1)
+    hit, rec = e.trace(o, d)
+    h2, r2 = oracle_default.trace(o, d)
+    assert_bits(hit, h2, "default scene, grazing rays: ids")
+    assert_bits(rec[:, 0], r2[:, 0], "default scene, grazing rays: distances")
+    keys = np.arange(len(o), dtype=np.uint32) * 2654435761 + 17
+    assert_bits(e.ray_color(o, d, 3, keys), oracle_default.ray_color(o, d, 3, keys), "default scene, grazing rays: radiance (LDS variant)")
+
+    n, key = int(golden("scene_synthetic")["n"]), int(golden("scene_synthetic")["build_key"])
+    obj, tex, mat = synthetic_tables(n)
+    plane = [[0.0, len(mat) - 1]]
+    scene = build_table_scene(rt.Scene(), tex, mat, obj, plane, None, None, assets["sky"], key)
+    osc = build_table_scene(orc.Scene(orc.MATH_PORTABLE), tex, mat, obj, plane, None, None, assets["sky"], key)
+    boxes = scene.dump_top()[0]
+    o, d = _grazing_rays(boxes[:: max(1, len(boxes) // 400)], 6, 2)
+    e2 = make_engine(rt, scene, 64, 64, 1, 1)
+    hit, rec = e2.trace(o, d)
+    h2, r2 = osc.trace(o, d)
+    assert_bits(hit, h2, "synthetic scene, grazing rays: ids")
+    assert_bits(rec[:, 0], r2[:, 0], "synthetic scene, grazing rays: distances")
