@@ -408,215 +408,235 @@ __device__ __forceinline__ void walker_start(const Scene& sc, const Store& st, W
 //     surrounding control flow is wave-uniform.
 // v2..v21 are used as scratch registers by name because the halves of a register pair cannot be named through operands.
 // Every lane of the wave must be enabled at the call.
+// RT_PROFILE builds (make PROF=1) time the phases of every round with the shader clock; see intersect_kernel
+struct Prof { unsigned long long box = 0, prim = 0, special = 0, refill = 0; unsigned rounds = 0, prims = 0, prim_lanes = 0, specials = 0, box_iters = 0, box_lanes = 0; };
+#ifdef RT_PROFILE
+#define RT_PROF(x) x
+#else
+#define RT_PROF(x)
+#endif
+#ifdef RT_PROFILE   // iterations of the loop and lanes that moved, summed per wave (the counters ride in two SGPRs)
+#define RT_BOX_COUNT "s_add_u32 %[iters], %[iters], 1\n\ts_bcnt1_i32_b64 %[cntS], %[mall]\n\ts_add_u32 %[lanes], %[lanes], %[cntS]\n\t"
+#define RT_BOX_COUNT_OPERANDS , [iters] "+s"(box_iters), [lanes] "+s"(box_lanes)
+#else
+#define RT_BOX_COUNT
+#define RT_BOX_COUNT_OPERANDS
+#endif
 template <bool LDS>
-__device__ __forceinline__ void box_steps(const Store& st, Walker& w, int quorum) {
+__device__ __forceinline__ void box_steps(const Store& st, Walker& w, int quorum, Prof& prof) {
     const unsigned long long px = __ballot(w.p3.x >= 0), py = __ballot(w.p3.y >= 0), pz = __ballot(w.p4.x >= 0);
     const unsigned long long usable = __ballot(w.usable);
     unsigned long long m, m2, m3, mall, saved;
     int n_inner;
+    RT_PROF(int box_iters = 0; int box_lanes = 0;)
     if (LDS) {
         const uint32_t base = (uint32_t)(uintptr_t)st.ent;   // LDS addresses are 32-bit offsets
         asm volatile(
-                 "s_mov_b64 %13, exec\n\t"
+                 "s_mov_b64 %[saved], exec\n\t"
                  "1:\n\t"
-                 "v_cmp_gt_u32_e32 vcc, 0x10000000, %3\n\t"
-                 "s_and_b64 %9, vcc, %24\n\t"
-                 "v_add_u32_e32 v9, 0xf0000000, %3\n\t"
-                 "v_cmp_gt_u32_e64 %10, 3, %8\n\t"
+                 "v_cmp_gt_u32_e32 vcc, 0x10000000, %[sk]\n\t"
+                 "s_and_b64 %[m], vcc, %[usable]\n\t"
+                 "v_add_u32_e32 v9, 0xf0000000, %[sk]\n\t"
+                 "v_cmp_gt_u32_e64 %[m2], 3, %[cnt]\n\t"
                  "v_cmp_gt_u32_e32 vcc, 0x30000000, v9\n\t"
-                 "s_and_b64 %10, %10, vcc\n\t"
-                 "s_or_b64 %12, %9, %10\n\t"
-                 "s_cmp_eq_u64 %12, 0\n\t"
+                 "s_and_b64 %[m2], %[m2], vcc\n\t"
+                 "s_or_b64 %[mall], %[m], %[m2]\n\t"
+                 "s_cmp_eq_u64 %[mall], 0\n\t"
                  "s_cbranch_scc1 2f\n\t"
-                 "s_cmp_eq_u64 %9, 0\n\t"
+                 "s_cmp_eq_u64 %[m], 0\n\t"
                  "s_cbranch_scc1 3f\n\t"
-                 "s_and_b64 exec, %13, %9\n\t"
-                 "v_pk_add_f32 v[10:11], %0, %15 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-                 "v_pk_add_f32 v[12:13], %1, %15 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-                 "v_pk_add_f32 v[14:15], %2, %16 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-                 "v_pk_mul_f32 v[2:3], v[10:11], %16 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
-                 "v_pk_mul_f32 v[4:5], v[12:13], %17 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
-                 "v_pk_mul_f32 v[6:7], v[14:15], %17 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
-                 "v_cndmask_b32_e64 v8, v3, v2, %20\n\t"
-                 "v_cndmask_b32_e64 v3, v2, v3, %20\n\t"
-                 "v_cndmask_b32_e64 v2, v5, v4, %21\n\t"
-                 "v_cndmask_b32_e64 v5, v4, v5, %21\n\t"
-                 "v_cndmask_b32_e64 v4, v7, v6, %22\n\t"
-                 "v_cndmask_b32_e64 v7, v6, v7, %22\n\t"
+                 "s_and_b64 exec, %[saved], %[m]\n\t"
+                 "v_pk_add_f32 v[10:11], %[e01], %[p0] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                 "v_pk_add_f32 v[12:13], %[e23], %[p0] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                 "v_pk_add_f32 v[14:15], %[e45], %[p1] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                 "v_pk_mul_f32 v[2:3], v[10:11], %[p1] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                 "v_pk_mul_f32 v[4:5], v[12:13], %[p2] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+                 "v_pk_mul_f32 v[6:7], v[14:15], %[p2] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                 "v_cndmask_b32_e64 v8, v3, v2, %[px]\n\t"
+                 "v_cndmask_b32_e64 v3, v2, v3, %[px]\n\t"
+                 "v_cndmask_b32_e64 v2, v5, v4, %[py]\n\t"
+                 "v_cndmask_b32_e64 v5, v4, v5, %[py]\n\t"
+                 "v_cndmask_b32_e64 v4, v7, v6, %[pz]\n\t"
+                 "v_cndmask_b32_e64 v7, v6, v7, %[pz]\n\t"
                  "v_max3_f32 v8, v8, v2, v4\n\t"
                  "v_min3_f32 v3, v3, v5, v7\n\t"
                  "v_cmp_le_f32_e32 vcc, v8, v3\n\t"
-                 "v_cmp_nlt_f32_e64 %11, v3, 0\n\t"
+                 "v_cmp_nlt_f32_e64 %[m3], v3, 0\n\t"
                  "v_sub_f32_e32 v9, v3, v8\n\t"
                  "v_max_f32_e64 v2, |v8|, |v3|\n\t"
-                 "s_and_b64 vcc, vcc, %11\n\t"
+                 "s_and_b64 vcc, vcc, %[m3]\n\t"
                  "v_mul_f32_e32 v2, 0x35800000, v2\n\t"
-                 "v_add_u32_e32 v4, 1, %4\n\t"
-                 "v_cmp_le_f32_e64 %11, |v9|, v2\n\t"
-                 "s_cmp_eq_u64 %11, 0\n\t"
+                 "v_add_u32_e32 v4, 1, %[i]\n\t"
+                 "v_cmp_le_f32_e64 %[m3], |v9|, v2\n\t"
+                 "s_cmp_eq_u64 %[m3], 0\n\t"
                  "s_cbranch_scc1 5f\n\t"
-                 "v_pk_mul_f32 v[2:3], v[10:11], %16 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
-                 "v_pk_mul_f32 v[4:5], v[12:13], %17 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
-                 "v_pk_mul_f32 v[6:7], v[14:15], %17 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
-                 "v_pk_fma_f32 v[16:17], %18, v[2:3], v[10:11] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 v[18:19], %18, v[4:5], v[12:13] op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 v[20:21], %19, v[6:7], v[14:15] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 v[2:3], v[16:17], %16, v[2:3] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                 "v_pk_fma_f32 v[4:5], v[18:19], %17, v[4:5] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
-                 "v_pk_fma_f32 v[6:7], v[20:21], %17, v[6:7] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                 "v_pk_fma_f32 v[16:17], %18, v[2:3], v[10:11] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 v[18:19], %18, v[4:5], v[12:13] op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 v[20:21], %19, v[6:7], v[14:15] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 v[2:3], v[16:17], %16, v[2:3] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                 "v_pk_fma_f32 v[4:5], v[18:19], %17, v[4:5] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
-                 "v_pk_fma_f32 v[6:7], v[20:21], %17, v[6:7] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                 "v_cndmask_b32_e64 v8, v3, v2, %20\n\t"
-                 "v_cndmask_b32_e64 v3, v2, v3, %20\n\t"
-                 "v_cndmask_b32_e64 v2, v5, v4, %21\n\t"
-                 "v_cndmask_b32_e64 v5, v4, v5, %21\n\t"
-                 "v_cndmask_b32_e64 v4, v7, v6, %22\n\t"
-                 "v_cndmask_b32_e64 v7, v6, v7, %22\n\t"
+                 "v_pk_mul_f32 v[2:3], v[10:11], %[p1] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                 "v_pk_mul_f32 v[4:5], v[12:13], %[p2] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+                 "v_pk_mul_f32 v[6:7], v[14:15], %[p2] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                 "v_pk_fma_f32 v[16:17], %[p3], v[2:3], v[10:11] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[18:19], %[p3], v[4:5], v[12:13] op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[20:21], %[p4], v[6:7], v[14:15] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[2:3], v[16:17], %[p1], v[2:3] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 v[4:5], v[18:19], %[p2], v[4:5] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 v[6:7], v[20:21], %[p2], v[6:7] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 v[16:17], %[p3], v[2:3], v[10:11] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[18:19], %[p3], v[4:5], v[12:13] op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[20:21], %[p4], v[6:7], v[14:15] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[2:3], v[16:17], %[p1], v[2:3] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 v[4:5], v[18:19], %[p2], v[4:5] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 v[6:7], v[20:21], %[p2], v[6:7] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_cndmask_b32_e64 v8, v3, v2, %[px]\n\t"
+                 "v_cndmask_b32_e64 v3, v2, v3, %[px]\n\t"
+                 "v_cndmask_b32_e64 v2, v5, v4, %[py]\n\t"
+                 "v_cndmask_b32_e64 v5, v4, v5, %[py]\n\t"
+                 "v_cndmask_b32_e64 v4, v7, v6, %[pz]\n\t"
+                 "v_cndmask_b32_e64 v7, v6, v7, %[pz]\n\t"
                  "v_max3_f32 v8, v8, v2, v4\n\t"
                  "v_min3_f32 v3, v3, v5, v7\n\t"
                  "v_cmp_le_f32_e32 vcc, v8, v3\n\t"
-                 "v_cmp_nlt_f32_e64 %11, v3, 0\n\t"
-                 "v_add_u32_e32 v4, 1, %4\n\t"
-                 "s_and_b64 vcc, vcc, %11\n\t"
+                 "v_cmp_nlt_f32_e64 %[m3], v3, 0\n\t"
+                 "v_add_u32_e32 v4, 1, %[i]\n\t"
+                 "s_and_b64 vcc, vcc, %[m3]\n\t"
                  "5:\n\t"
                  "s_nop 0\n\t"
-                 "v_cndmask_b32_e32 %4, %3, v4, vcc\n\t"
+                 "v_cndmask_b32_e32 %[i], %[sk], v4, vcc\n\t"
                  "3:\n\t"
-                 "s_cmp_eq_u64 %10, 0\n\t"
+                 "s_cmp_eq_u64 %[m2], 0\n\t"
                  "s_cbranch_scc1 4f\n\t"
-                 "s_and_b64 exec, %13, %10\n\t"
-                 "v_cmp_eq_u32_e64 %11, 0, %8\n\t"
-                 "v_cmp_eq_u32_e32 vcc, 1, %8\n\t"
-                 "v_mov_b32_e32 %7, %4\n\t"
-                 "v_add_u32_e32 %8, 1, %8\n\t"
-                 "v_cndmask_b32_e64 %5, %5, %4, %11\n\t"
-                 "v_cndmask_b32_e32 %6, %6, %4, vcc\n\t"
-                 "v_add_u32_e32 %4, 1, %4\n\t"
+                 "s_and_b64 exec, %[saved], %[m2]\n\t"
+                 "v_cmp_eq_u32_e64 %[m3], 0, %[cnt]\n\t"
+                 "v_cmp_eq_u32_e32 vcc, 1, %[cnt]\n\t"
+                 "v_mov_b32_e32 %[f2], %[i]\n\t"
+                 "v_add_u32_e32 %[cnt], 1, %[cnt]\n\t"
+                 "v_cndmask_b32_e64 %[f0], %[f0], %[i], %[m3]\n\t"
+                 "v_cndmask_b32_e32 %[f1], %[f1], %[i], vcc\n\t"
+                 "v_add_u32_e32 %[i], 1, %[i]\n\t"
                  "4:\n\t"
-                 "s_and_b64 exec, %13, %12\n\t"
-                 "v_lshl_add_u32 v2, %4, 5, %23\n\t"
-                 "ds_read_b64 %0, v2\n\t"
-                 "ds_read_b64 %1, v2 offset:8\n\t"
-                 "ds_read_b64 %2, v2 offset:16\n\t"
-                 "ds_read_b32 %3, v2 offset:24\n\t"
+                 "s_and_b64 exec, %[saved], %[mall]\n\t"
+                 RT_BOX_COUNT
+                 "v_lshl_add_u32 v2, %[i], 5, %[base]\n\t"
+                 "ds_read_b64 %[e01], v2\n\t"
+                 "ds_read_b64 %[e23], v2 offset:8\n\t"
+                 "ds_read_b64 %[e45], v2 offset:16\n\t"
+                 "ds_read_b32 %[sk], v2 offset:24\n\t"
                  "s_waitcnt lgkmcnt(0)\n\t"
-                 "s_mov_b64 exec, %13\n\t"
-                 "s_bcnt1_i32_b64 %14, %9\n\t"
-                 "s_cmp_ge_u32 %14, %25\n\t"
+                 "s_mov_b64 exec, %[saved]\n\t"
+                 "s_bcnt1_i32_b64 %[cntS], %[m]\n\t"
+                 "s_cmp_ge_u32 %[cntS], %[quorum]\n\t"
                  "s_cbranch_scc1 1b\n\t"
                  "2:\n\t"
-                 : "+v"(w.e01), "+v"(w.e23), "+v"(w.e45), "+v"(w.sk), "+v"(w.i), "+v"(w.f0), "+v"(w.f1), "+v"(w.f2), "+v"(w.cnt),
-                   "=&s"(m), "=&s"(m2), "=&s"(m3), "=&s"(mall), "=&s"(saved), "=&s"(n_inner)
-                 : "v"(w.p0), "v"(w.p1), "v"(w.p2), "v"(w.p3), "v"(w.p4), "s"(px), "s"(py), "s"(pz), "s"(base), "s"(usable),
-                   "s"(quorum)
+                 : [e01] "+v"(w.e01), [e23] "+v"(w.e23), [e45] "+v"(w.e45), [sk] "+v"(w.sk), [i] "+v"(w.i), [f0] "+v"(w.f0),
+                   [f1] "+v"(w.f1), [f2] "+v"(w.f2), [cnt] "+v"(w.cnt), [m] "=&s"(m), [m2] "=&s"(m2), [m3] "=&s"(m3),
+                   [mall] "=&s"(mall), [saved] "=&s"(saved), [cntS] "=&s"(n_inner) RT_BOX_COUNT_OPERANDS
+                 : [p0] "v"(w.p0), [p1] "v"(w.p1), [p2] "v"(w.p2), [p3] "v"(w.p3), [p4] "v"(w.p4), [px] "s"(px), [py] "s"(py),
+                   [pz] "s"(pz), [base] "s"(base), [usable] "s"(usable), [quorum] "s"(quorum)
                  : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18",
                    "v19", "v20", "v21", "vcc", "scc", "memory");
     } else {
         const float4* base = st.ent;
         asm volatile(
-                 "s_mov_b64 %13, exec\n\t"
+                 "s_mov_b64 %[saved], exec\n\t"
                  "1:\n\t"
-                 "v_cmp_gt_u32_e32 vcc, 0x10000000, %3\n\t"
-                 "s_and_b64 %9, vcc, %24\n\t"
-                 "v_add_u32_e32 v9, 0xf0000000, %3\n\t"
-                 "v_cmp_gt_u32_e64 %10, 3, %8\n\t"
+                 "v_cmp_gt_u32_e32 vcc, 0x10000000, %[sk]\n\t"
+                 "s_and_b64 %[m], vcc, %[usable]\n\t"
+                 "v_add_u32_e32 v9, 0xf0000000, %[sk]\n\t"
+                 "v_cmp_gt_u32_e64 %[m2], 3, %[cnt]\n\t"
                  "v_cmp_gt_u32_e32 vcc, 0x30000000, v9\n\t"
-                 "s_and_b64 %10, %10, vcc\n\t"
-                 "s_or_b64 %12, %9, %10\n\t"
-                 "s_cmp_eq_u64 %12, 0\n\t"
+                 "s_and_b64 %[m2], %[m2], vcc\n\t"
+                 "s_or_b64 %[mall], %[m], %[m2]\n\t"
+                 "s_cmp_eq_u64 %[mall], 0\n\t"
                  "s_cbranch_scc1 2f\n\t"
-                 "s_cmp_eq_u64 %9, 0\n\t"
+                 "s_cmp_eq_u64 %[m], 0\n\t"
                  "s_cbranch_scc1 3f\n\t"
-                 "s_and_b64 exec, %13, %9\n\t"
-                 "v_pk_add_f32 v[10:11], %0, %15 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-                 "v_pk_add_f32 v[12:13], %1, %15 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-                 "v_pk_add_f32 v[14:15], %2, %16 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-                 "v_pk_mul_f32 v[2:3], v[10:11], %16 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
-                 "v_pk_mul_f32 v[4:5], v[12:13], %17 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
-                 "v_pk_mul_f32 v[6:7], v[14:15], %17 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
-                 "v_cndmask_b32_e64 v8, v3, v2, %20\n\t"
-                 "v_cndmask_b32_e64 v3, v2, v3, %20\n\t"
-                 "v_cndmask_b32_e64 v2, v5, v4, %21\n\t"
-                 "v_cndmask_b32_e64 v5, v4, v5, %21\n\t"
-                 "v_cndmask_b32_e64 v4, v7, v6, %22\n\t"
-                 "v_cndmask_b32_e64 v7, v6, v7, %22\n\t"
+                 "s_and_b64 exec, %[saved], %[m]\n\t"
+                 "v_pk_add_f32 v[10:11], %[e01], %[p0] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                 "v_pk_add_f32 v[12:13], %[e23], %[p0] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                 "v_pk_add_f32 v[14:15], %[e45], %[p1] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                 "v_pk_mul_f32 v[2:3], v[10:11], %[p1] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                 "v_pk_mul_f32 v[4:5], v[12:13], %[p2] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+                 "v_pk_mul_f32 v[6:7], v[14:15], %[p2] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                 "v_cndmask_b32_e64 v8, v3, v2, %[px]\n\t"
+                 "v_cndmask_b32_e64 v3, v2, v3, %[px]\n\t"
+                 "v_cndmask_b32_e64 v2, v5, v4, %[py]\n\t"
+                 "v_cndmask_b32_e64 v5, v4, v5, %[py]\n\t"
+                 "v_cndmask_b32_e64 v4, v7, v6, %[pz]\n\t"
+                 "v_cndmask_b32_e64 v7, v6, v7, %[pz]\n\t"
                  "v_max3_f32 v8, v8, v2, v4\n\t"
                  "v_min3_f32 v3, v3, v5, v7\n\t"
                  "v_cmp_le_f32_e32 vcc, v8, v3\n\t"
-                 "v_cmp_nlt_f32_e64 %11, v3, 0\n\t"
+                 "v_cmp_nlt_f32_e64 %[m3], v3, 0\n\t"
                  "v_sub_f32_e32 v9, v3, v8\n\t"
                  "v_max_f32_e64 v2, |v8|, |v3|\n\t"
-                 "s_and_b64 vcc, vcc, %11\n\t"
+                 "s_and_b64 vcc, vcc, %[m3]\n\t"
                  "v_mul_f32_e32 v2, 0x35800000, v2\n\t"
-                 "v_add_u32_e32 v4, 1, %4\n\t"
-                 "v_cmp_le_f32_e64 %11, |v9|, v2\n\t"
-                 "s_cmp_eq_u64 %11, 0\n\t"
+                 "v_add_u32_e32 v4, 1, %[i]\n\t"
+                 "v_cmp_le_f32_e64 %[m3], |v9|, v2\n\t"
+                 "s_cmp_eq_u64 %[m3], 0\n\t"
                  "s_cbranch_scc1 5f\n\t"
-                 "v_pk_mul_f32 v[2:3], v[10:11], %16 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
-                 "v_pk_mul_f32 v[4:5], v[12:13], %17 op_sel:[0,0] op_sel_hi:[1,0]\n\t"
-                 "v_pk_mul_f32 v[6:7], v[14:15], %17 op_sel:[0,1] op_sel_hi:[1,1]\n\t"
-                 "v_pk_fma_f32 v[16:17], %18, v[2:3], v[10:11] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 v[18:19], %18, v[4:5], v[12:13] op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 v[20:21], %19, v[6:7], v[14:15] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 v[2:3], v[16:17], %16, v[2:3] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                 "v_pk_fma_f32 v[4:5], v[18:19], %17, v[4:5] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
-                 "v_pk_fma_f32 v[6:7], v[20:21], %17, v[6:7] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                 "v_pk_fma_f32 v[16:17], %18, v[2:3], v[10:11] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 v[18:19], %18, v[4:5], v[12:13] op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 v[20:21], %19, v[6:7], v[14:15] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 v[2:3], v[16:17], %16, v[2:3] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                 "v_pk_fma_f32 v[4:5], v[18:19], %17, v[4:5] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
-                 "v_pk_fma_f32 v[6:7], v[20:21], %17, v[6:7] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                 "v_cndmask_b32_e64 v8, v3, v2, %20\n\t"
-                 "v_cndmask_b32_e64 v3, v2, v3, %20\n\t"
-                 "v_cndmask_b32_e64 v2, v5, v4, %21\n\t"
-                 "v_cndmask_b32_e64 v5, v4, v5, %21\n\t"
-                 "v_cndmask_b32_e64 v4, v7, v6, %22\n\t"
-                 "v_cndmask_b32_e64 v7, v6, v7, %22\n\t"
+                 "v_pk_mul_f32 v[2:3], v[10:11], %[p1] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                 "v_pk_mul_f32 v[4:5], v[12:13], %[p2] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+                 "v_pk_mul_f32 v[6:7], v[14:15], %[p2] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                 "v_pk_fma_f32 v[16:17], %[p3], v[2:3], v[10:11] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[18:19], %[p3], v[4:5], v[12:13] op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[20:21], %[p4], v[6:7], v[14:15] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[2:3], v[16:17], %[p1], v[2:3] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 v[4:5], v[18:19], %[p2], v[4:5] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 v[6:7], v[20:21], %[p2], v[6:7] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 v[16:17], %[p3], v[2:3], v[10:11] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[18:19], %[p3], v[4:5], v[12:13] op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[20:21], %[p4], v[6:7], v[14:15] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[2:3], v[16:17], %[p1], v[2:3] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 v[4:5], v[18:19], %[p2], v[4:5] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 v[6:7], v[20:21], %[p2], v[6:7] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_cndmask_b32_e64 v8, v3, v2, %[px]\n\t"
+                 "v_cndmask_b32_e64 v3, v2, v3, %[px]\n\t"
+                 "v_cndmask_b32_e64 v2, v5, v4, %[py]\n\t"
+                 "v_cndmask_b32_e64 v5, v4, v5, %[py]\n\t"
+                 "v_cndmask_b32_e64 v4, v7, v6, %[pz]\n\t"
+                 "v_cndmask_b32_e64 v7, v6, v7, %[pz]\n\t"
                  "v_max3_f32 v8, v8, v2, v4\n\t"
                  "v_min3_f32 v3, v3, v5, v7\n\t"
                  "v_cmp_le_f32_e32 vcc, v8, v3\n\t"
-                 "v_cmp_nlt_f32_e64 %11, v3, 0\n\t"
-                 "v_add_u32_e32 v4, 1, %4\n\t"
-                 "s_and_b64 vcc, vcc, %11\n\t"
+                 "v_cmp_nlt_f32_e64 %[m3], v3, 0\n\t"
+                 "v_add_u32_e32 v4, 1, %[i]\n\t"
+                 "s_and_b64 vcc, vcc, %[m3]\n\t"
                  "5:\n\t"
                  "s_nop 0\n\t"
-                 "v_cndmask_b32_e32 %4, %3, v4, vcc\n\t"
+                 "v_cndmask_b32_e32 %[i], %[sk], v4, vcc\n\t"
                  "3:\n\t"
-                 "s_cmp_eq_u64 %10, 0\n\t"
+                 "s_cmp_eq_u64 %[m2], 0\n\t"
                  "s_cbranch_scc1 4f\n\t"
-                 "s_and_b64 exec, %13, %10\n\t"
-                 "v_cmp_eq_u32_e64 %11, 0, %8\n\t"
-                 "v_cmp_eq_u32_e32 vcc, 1, %8\n\t"
-                 "v_mov_b32_e32 %7, %4\n\t"
-                 "v_add_u32_e32 %8, 1, %8\n\t"
-                 "v_cndmask_b32_e64 %5, %5, %4, %11\n\t"
-                 "v_cndmask_b32_e32 %6, %6, %4, vcc\n\t"
-                 "v_add_u32_e32 %4, 1, %4\n\t"
+                 "s_and_b64 exec, %[saved], %[m2]\n\t"
+                 "v_cmp_eq_u32_e64 %[m3], 0, %[cnt]\n\t"
+                 "v_cmp_eq_u32_e32 vcc, 1, %[cnt]\n\t"
+                 "v_mov_b32_e32 %[f2], %[i]\n\t"
+                 "v_add_u32_e32 %[cnt], 1, %[cnt]\n\t"
+                 "v_cndmask_b32_e64 %[f0], %[f0], %[i], %[m3]\n\t"
+                 "v_cndmask_b32_e32 %[f1], %[f1], %[i], vcc\n\t"
+                 "v_add_u32_e32 %[i], 1, %[i]\n\t"
                  "4:\n\t"
-                 "s_and_b64 exec, %13, %12\n\t"
-                 "v_lshlrev_b32_e32 v2, 5, %4\n\t"
-                 "global_load_dwordx2 %0, v2, %23\n\t"
-                 "global_load_dwordx2 %1, v2, %23 offset:8\n\t"
-                 "global_load_dwordx2 %2, v2, %23 offset:16\n\t"
-                 "global_load_dword %3, v2, %23 offset:24\n\t"
+                 "s_and_b64 exec, %[saved], %[mall]\n\t"
+                 RT_BOX_COUNT
+                 "v_lshlrev_b32_e32 v2, 5, %[i]\n\t"
+                 "global_load_dwordx2 %[e01], v2, %[base]\n\t"
+                 "global_load_dwordx2 %[e23], v2, %[base] offset:8\n\t"
+                 "global_load_dwordx2 %[e45], v2, %[base] offset:16\n\t"
+                 "global_load_dword %[sk], v2, %[base] offset:24\n\t"
                  "s_waitcnt vmcnt(0)\n\t"
-                 "s_mov_b64 exec, %13\n\t"
-                 "s_bcnt1_i32_b64 %14, %9\n\t"
-                 "s_cmp_ge_u32 %14, %25\n\t"
+                 "s_mov_b64 exec, %[saved]\n\t"
+                 "s_bcnt1_i32_b64 %[cntS], %[m]\n\t"
+                 "s_cmp_ge_u32 %[cntS], %[quorum]\n\t"
                  "s_cbranch_scc1 1b\n\t"
                  "2:\n\t"
-                 : "+v"(w.e01), "+v"(w.e23), "+v"(w.e45), "+v"(w.sk), "+v"(w.i), "+v"(w.f0), "+v"(w.f1), "+v"(w.f2), "+v"(w.cnt),
-                   "=&s"(m), "=&s"(m2), "=&s"(m3), "=&s"(mall), "=&s"(saved), "=&s"(n_inner)
-                 : "v"(w.p0), "v"(w.p1), "v"(w.p2), "v"(w.p3), "v"(w.p4), "s"(px), "s"(py), "s"(pz), "s"(base), "s"(usable),
-                   "s"(quorum)
+                 : [e01] "+v"(w.e01), [e23] "+v"(w.e23), [e45] "+v"(w.e45), [sk] "+v"(w.sk), [i] "+v"(w.i), [f0] "+v"(w.f0),
+                   [f1] "+v"(w.f1), [f2] "+v"(w.f2), [cnt] "+v"(w.cnt), [m] "=&s"(m), [m2] "=&s"(m2), [m3] "=&s"(m3),
+                   [mall] "=&s"(mall), [saved] "=&s"(saved), [cntS] "=&s"(n_inner) RT_BOX_COUNT_OPERANDS
+                 : [p0] "v"(w.p0), [p1] "v"(w.p1), [p2] "v"(w.p2), [p3] "v"(w.p3), [p4] "v"(w.p4), [px] "s"(px), [py] "s"(py),
+                   [pz] "s"(pz), [base] "s"(base), [usable] "s"(usable), [quorum] "s"(quorum)
                  : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18",
                    "v19", "v20", "v21", "vcc", "scc", "memory");
     }
+    RT_PROF(prof.box_iters += box_iters; prof.box_lanes += box_lanes;)
 }
 
 // The oldest noted leaf of the lane: Sphere / AxisAlignedCube / Triangle ::Intersect and the closest-hit bookkeeping of
@@ -686,17 +706,10 @@ __device__ __forceinline__ bool walker_special(const Scene& sc, const Store& st,
 }
 // One round for a wave: the traversal loop; then primitive tests, repeated while at least `prim_quorum` lanes have a
 // noted leaf; then the state-changing entries of lanes that have none left.  Returns true in lanes whose ray finished.
-// RT_PROFILE builds (make PROF=1) time the phases of every round with the shader clock; see intersect_kernel
-struct Prof { unsigned long long box = 0, prim = 0, special = 0, refill = 0; unsigned rounds = 0, prims = 0, prim_lanes = 0, specials = 0; };
-#ifdef RT_PROFILE
-#define RT_PROF(x) x
-#else
-#define RT_PROF(x)
-#endif
 template <bool LDS>
 __device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Walker& w, int quorum, int prim_quorum, Prof& prof) {
     RT_PROF(unsigned long long t0 = __builtin_readcyclecounter(); prof.rounds++;)
-    box_steps<LDS>(st, w, quorum);
+    box_steps<LDS>(st, w, quorum, prof);
     RT_PROF(unsigned long long t1 = __builtin_readcyclecounter(); prof.box += t1 - t0;)
     for (;;) {
         const bool has = w.cnt != 0;

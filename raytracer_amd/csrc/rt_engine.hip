@@ -219,11 +219,12 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
     }
 #ifdef RT_PROFILE
     if (dbg.prof && lane == 0 && prof.rounds) {   // per pass: 12 counters summed over the waves that had work
-        unsigned long long* p = dbg.prof + 12 * (pass < 15 ? pass : 15);
+        unsigned long long* p = dbg.prof + 16 * (pass < 15 ? pass : 15);
         atomicAdd(p + 0, 1ull); atomicAdd(p + 1, __builtin_readcyclecounter() - t_start); atomicAdd(p + 2, (unsigned long long)prof.rounds);
         atomicAdd(p + 3, prof.box); atomicAdd(p + 4, prof.prim); atomicAdd(p + 5, prof.special); atomicAdd(p + 6, prof.refill);
         atomicAdd(p + 7, (unsigned long long)prof.prims); atomicAdd(p + 8, (unsigned long long)prof.prim_lanes);
         atomicAdd(p + 9, (unsigned long long)prof.specials); atomicAdd(p + 10, (unsigned long long)n_refills);
+        atomicAdd(p + 11, (unsigned long long)prof.box_iters); atomicAdd(p + 12, (unsigned long long)prof.box_lanes);
     }
 #endif
 }
@@ -606,8 +607,8 @@ int rt_engine_create(const rt_config* cfg, rt_engine** out) {
     HIP_TRY(hipMemset(e->d_frame, 0, (size_t)cfg->width * cfg->height * 4));
     e->n_counts = cfg->bounces + 2;
 #ifdef RT_PROFILE
-    HIP_TRY(hipMalloc((void**)&e->dbg.prof, sizeof(unsigned long long) * 16 * 12));
-    HIP_TRY(hipMemset(e->dbg.prof, 0, sizeof(unsigned long long) * 16 * 12));
+    HIP_TRY(hipMalloc((void**)&e->dbg.prof, sizeof(unsigned long long) * 16 * 16));
+    HIP_TRY(hipMemset(e->dbg.prof, 0, sizeof(unsigned long long) * 16 * 16));
 #endif
     if (const char* v = getenv("RT_REFILL_AT")) e->tune.refill_at = std::max(1, std::min(64, atoi(v)));
     if (const char* v = getenv("RT_QUORUM")) e->tune.quorum = std::max(1, std::min(65, atoi(v)));
@@ -980,16 +981,17 @@ int rt_engine_get_stats(rt_engine* e, rt_stats* out) {
         for (int k = 1; k < nc - 1 && k < 33; k++) out->rays_at_depth[k] += e->h_counts[(size_t)b * per_batch + k];
 #ifdef RT_PROFILE
     if (e->dbg.prof) {
-        unsigned long long h[16 * 12];
+        unsigned long long h[16 * 16];
         HIP_TRY(hipMemcpy(h, e->dbg.prof, sizeof h, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemset(e->dbg.prof, 0, sizeof h));
         fprintf(stderr, "pass waves cycles/wave rounds/wave box%% prim%% special%% refill%% prim_steps/wave lanes/prim_step specials/wave refills/wave (all renders since the last call)\n");
         for (int k = 0; k < 16; k++) {
-            const unsigned long long* p = h + 12 * k;
+            const unsigned long long* p = h + 16 * k;
             if (!p[0]) continue;
             const double w = (double)p[0], cyc = (double)p[1];
-            fprintf(stderr, "%2d %6llu %9.0f %7.1f %5.1f %5.1f %5.1f %5.1f %7.1f %5.1f %6.1f %6.1f\n", k, p[0], cyc / w, p[2] / w, 100.0 * p[3] / cyc,
-                    100.0 * p[4] / cyc, 100.0 * p[5] / cyc, 100.0 * p[6] / cyc, p[7] / w, p[7] ? (double)p[8] / p[7] : 0.0, p[9] / w, p[10] / w);
+            const double iters = (double)p[11], lanes = (double)p[12];
+            fprintf(stderr, "%2d %6llu %9.0f %7.1f %5.1f %5.1f %5.1f %5.1f %7.1f %5.1f %6.1f %6.1f  box iters/wave %.0f lanes/iter %.1f\n", k, p[0], cyc / w, p[2] / w, 100.0 * p[3] / cyc,
+                    100.0 * p[4] / cyc, 100.0 * p[5] / cyc, 100.0 * p[6] / cyc, p[7] / w, p[7] ? (double)p[8] / p[7] : 0.0, p[9] / w, p[10] / w, iters / w, iters ? lanes / iters : 0.0);
         }
     }
 #endif
