@@ -116,6 +116,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--batch-paths", type=int, default=0)
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 ranks all on GPU 0 with a gloo group (staged through the host): checks the multi-process "
+                         "path on a one-GPU box; the number it prints is not a measurement")
     args = ap.parse_args()
 
     import torch
@@ -130,11 +133,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run --nproc-per-node N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP engine is the only compute path")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    red_device = torch.device("cpu") if args.rehearse_on_one_gpu else device     # where the timing reductions live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     desc, W, H, S, B = WORKLOADS[args.workload]
     scene, cam = build_scene(rt, args.workload)
@@ -163,9 +172,9 @@ def main():
     eng.time_kernels(False)
     st = eng.stats()                       # this rank's share of one frame (every step renders the same frame)
 
-    t = torch.tensor([dt], dtype=torch.float64, device=device)
-    counts = torch.tensor([st["rays"], st["paths"]], dtype=torch.float64, device=device)
-    kt = torch.tensor([kern_ms], dtype=torch.float64, device=device)
+    t = torch.tensor([dt], dtype=torch.float64, device=red_device)
+    counts = torch.tensor([st["rays"], st["paths"]], dtype=torch.float64, device=red_device)
+    kt = torch.tensor([kern_ms], dtype=torch.float64, device=red_device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(counts, op=dist.ReduceOp.SUM)
@@ -190,7 +199,7 @@ def main():
         out = {
             "metric": "Mrays/s", "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic" if not args.rehearse_on_one_gpu else "synthetic (rehearsal: all ranks on one GPU, not a measurement)",
             "config": {"workload": desc, "width": W, "height": H, "spp": S * S, "bounces": B, "rays_per_frame": rays_frame,
                        "paths_per_frame": paths_frame, "parallelism": f"tiles{world}", "batch_paths": eng.cfg.max_batch_paths},
             "ms_per_frame": dt / args.steps * 1e3,

@@ -21,6 +21,8 @@ class TileRenderer:
         self.rank, self.world, self.group, self.display = rank, world_size, group, display_rank
         W, H = engine.cfg.width, engine.cfg.height
         self.frame = torch.zeros(H * W * 4, dtype=torch.uint8, device=self.device) if rank == display_rank or world_size == 1 else None
+        # a gloo group cannot gather device tensors: rehearsals of the multi-process path on GPUs stage through the host
+        self.via_host = world_size > 1 and self.device.type == "cuda" and dist.get_backend(group) == "gloo"
         if world_size > 1:
             self.nb = engine.tile_bytes(world_size)
             self.mine = torch.zeros(self.nb, dtype=torch.uint8, device=self.device)
@@ -36,6 +38,17 @@ class TileRenderer:
             self.e.render(seed, 0, 1, self.frame.data_ptr(), st)
             return self.frame
         self.e.render(seed, self.rank, self.world, self.mine.data_ptr(), st)
+        if self.via_host:
+            torch.cuda.current_stream(self.device).synchronize()
+            mine = self.mine.cpu()
+            if self.rank == self.display:
+                parts = [torch.empty_like(mine) for _ in range(self.world)]
+                dist.gather(mine, parts, dst=self.display, group=self.group)
+                self.gathered.copy_(torch.cat(parts))
+                self.e.assemble(self.gathered.data_ptr(), self.world, self.frame.data_ptr(), st)
+                return self.frame
+            dist.gather(mine, None, dst=self.display, group=self.group)
+            return None
         if self.rank == self.display:
             dist.gather(self.mine, list(self.gathered.chunk(self.world)), dst=self.display, group=self.group)
             self.e.assemble(self.gathered.data_ptr(), self.world, self.frame.data_ptr(), st)
