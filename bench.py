@@ -28,6 +28,10 @@ WORKLOADS = {
     "c1": ("default scene 1280x720, 9 spp, 3 bounces (the reference's Constants.h)", 1280, 720, 3, 3),
     "c2": ("default scene 1920x1080, 64 spp, 8 bounces", 1920, 1080, 8, 8),
     "c3": ("synthetic 100k sphere/box scene 3840x2160, 256 spp, 8 bounces", 3840, 2160, 16, 8),
+    # interactive sequence: the camera moves every frame as the front end's input handler would move it (App.cpp:98,
+    # 114-137: mouse (3, 1) per frame, key W for frames 0-119, D for 120-239); every frame is waited for, so a step's
+    # time is the latency a viewer sees, gather included
+    "c5": ("default scene 1920x1080, 9 spp, 3 bounces, 240-frame camera path, one frame in flight", 1920, 1080, 3, 3),
 }
 # FLOPs the reference algorithm spends per counted event (sqrt and divide count 1, compares and libm calls excluded).
 # The events of the closest-hit query (and, for primary rays, camera-ray generation) are the work of intersect_kernel,
@@ -45,12 +49,12 @@ PEAK_FP32_TFLOPS = 157.3     # MI355X vector FP32 with packed FMA; unfused scala
 PEAK_HBM_GBS = 8000.0
 # per-ray figures of the reference algorithm measured by the oracle's event counters over the CPU sample of each workload;
 # used when the CPU leg is skipped (--no-cpu-baseline, N > 1)
-FALLBACK_FLOP_PER_RAY = {"c1": 1002.0, "c2": 1002.0, "c3": 7000.0}
-FALLBACK_SCENE_BYTE_PER_RAY = {"c1": 1480.0, "c2": 1480.0, "c3": 13400.0}
+FALLBACK_FLOP_PER_RAY = {"c1": 1002.0, "c2": 1002.0, "c3": 7000.0, "c5": 1002.0}
+FALLBACK_SCENE_BYTE_PER_RAY = {"c1": 1480.0, "c2": 1480.0, "c3": 13400.0, "c5": 1480.0}
 
 
 def build_scene(rt, workload):
-    if workload in ("c1", "c2"):
+    if workload in ("c1", "c2", "c5"):
         return rt.default_scene(BUILD_KEY), rt.camera_look(*CAM_DEFAULT)
     from raytracer_amd.synthetic import synthetic_scene
     return synthetic_scene(rt, 100000, BUILD_KEY + 2), rt.camera_look((0.0, 20.0, -150.0), (0.0, 0.0, 1.0))
@@ -65,7 +69,7 @@ def cpu_baseline(workload, W, H, S, B, threads):
     asset = os.path.join(E.ASSET_DIR, "src", "stb_image")
     sky, _ = E.load_png(os.path.join(asset, "skybox12.png"), 3)
     s = O.Scene(O.MATH_LIBM)
-    if workload in ("c1", "c2"):
+    if workload in ("c1", "c2", "c5"):
         verts = E.load_obj(os.path.join(asset, "tree.obj"))
         tex, _ = E.load_png(os.path.join(asset, "tree_texture.png"), 4)
         s.default_scene(verts, tex, sky)
@@ -77,7 +81,7 @@ def cpu_baseline(workload, W, H, S, B, threads):
         build_from_tables(s, tex_t, mat_t, obj, [[0.0, len(mat_t) - 1]], sky, BUILD_KEY + 2)
         cam = O.camera((0.0, 20.0, -150.0), (0.0, 0.0, 1.0))
     # sized for roughly 10-30 s on 16 host threads: the whole frame for c1/c2, a few row segments for c3
-    n_strips, rows = {"c1": (1, H), "c2": (1, H), "c3": (4, 1)}[workload]
+    n_strips, rows = {"c1": (1, H), "c2": (1, H), "c3": (4, 1), "c5": (1, H)}[workload]
     s.counters(reset=True)
     t0 = time.perf_counter()
     px = 0
@@ -159,13 +163,23 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(device)
 
+    frame_ms = []
     for _ in range(args.warmup):
         tr.render_frame(SEED)
     barrier()
     eng.time_kernels(True)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tr.render_frame(SEED)
+    if args.workload == "c5":
+        for f in range(args.steps):
+            cam = rt.camera_input(cam, 3.0, 1.0, w=int(f % 240 < 120), d=int(f % 240 >= 120))
+            eng.set_camera(cam)
+            t1 = time.perf_counter()
+            tr.render_frame(SEED + f)
+            barrier()
+            frame_ms.append((time.perf_counter() - t1) * 1e3)
+    else:
+        for _ in range(args.steps):
+            tr.render_frame(SEED)
     barrier()
     dt = time.perf_counter() - t0
     kern_ms, kern_launches = eng.kernel_times()
@@ -203,6 +217,8 @@ def main():
             "config": {"workload": desc, "width": W, "height": H, "spp": S * S, "bounces": B, "rays_per_frame": rays_frame,
                        "paths_per_frame": paths_frame, "parallelism": f"tiles{world}", "batch_paths": eng.cfg.max_batch_paths},
             "ms_per_frame": dt / args.steps * 1e3,
+            "frame_latency_ms": ({"p50": float(np.percentile(frame_ms, 50)), "p99": float(np.percentile(frame_ms, 99)),
+                                  "max": float(max(frame_ms))} if frame_ms else None),
             "roofline": {"bound": "valu", "achieved": ach_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                          "frac": (ach_tflops / PEAK_FP32_TFLOPS) if ach_tflops else None, "traffic": None,
                          # the reference's unfused, unpacked arithmetic (kept for bit-exact ids) can issue 1/4 of the peak

@@ -292,7 +292,7 @@ __device__ __forceinline__ void from_instance(const float4 i0, const float4 i1, 
 // r = a - b*q exactly by FMA, q += r*y), five ordinary instructions instead of the ~11 of the hardware's IEEE sequence.
 // The scheme is exact (a zero quotient possibly with the other sign, which no comparison can tell) while nothing
 // over/underflows; `usable` below admits a ray only if that holds for every box of the scene: |dir| components in
-// [2^-20, 2^20], origin components 0 or in [2^-50, 2^40] — the host checks the same of all box coordinates
+// [2^-20, 2^20], origin components 0 or in [2^-50, 2^40] (dividends down to 2^-80 are still exact) — the host checks the same of all box coordinates
 // (Scene::fast_div_ok).  Other rays take true division.
 __device__ __forceinline__ float div_by(float a, float b, float y) {
     float q = a * y;
@@ -300,6 +300,14 @@ __device__ __forceinline__ float div_by(float a, float b, float y) {
     q = __builtin_fmaf(r, y, q);
     r = __builtin_fmaf(-b, q, a);
     return __builtin_fmaf(r, y, q);
+}
+// RN(1/d) for |d| in [2^-20, 2^20]: the hardware reciprocal refined by the FMA steps of the IEEE division sequence, without
+// that sequence's operand scaling and special-case fix-up, which do nothing in this range (seven instructions, not eleven)
+__device__ __forceinline__ float recip_in_range(float d) {
+    const float r0 = __builtin_amdgcn_rcpf(d);
+    const float r1 = __builtin_fmaf(__builtin_fmaf(-d, r0, 1.0f), r0, r0);
+    const float q = __builtin_fmaf(__builtin_fmaf(-d, r1, 1.0f), r1, r1);
+    return __builtin_fmaf(__builtin_fmaf(-d, q, 1.0f), r1, q);
 }
 __device__ __forceinline__ bool mag_in(float v, float lo, float hi) { const float a = fabsf(v); return a >= lo && a <= hi; }
 __device__ __forceinline__ bool coord_ok(float v) { return v == 0.0f || mag_in(v, 8.8817841970012523e-16f, 1.099511627776e12f); }
@@ -347,7 +355,8 @@ __device__ __forceinline__ Ray walker_ray(const Walker& w) {
 }
 __device__ __forceinline__ void walker_set_ray(Walker& w, const Ray& r, bool scene_ok) {
     w.usable = scene_ok && ray_usable(r);
-    w.p0 = f2{r.o.x, r.o.y}; w.p1 = f2{r.o.z, 1.0f / r.d.x}; w.p2 = f2{1.0f / r.d.y, 1.0f / r.d.z};
+    // the reciprocals are only used when the ray is admitted to the reciprocal path, i.e. |d| within [2^-20, 2^20]
+    w.p0 = f2{r.o.x, r.o.y}; w.p1 = f2{r.o.z, recip_in_range(r.d.x)}; w.p2 = f2{recip_in_range(r.d.y), recip_in_range(r.d.z)};
     w.p3 = f2{r.d.x, r.d.y}; w.p4 = f2{r.d.z, 0.0f};
 }
 __device__ __forceinline__ void walker_load(const Store& st, Walker& w) {

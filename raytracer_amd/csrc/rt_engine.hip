@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -69,7 +70,15 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv& f) {
 }
 
 struct Cam { V3 pos, fwd, u, v; };
-struct Cfg { int W, H, S, B; float fov, sky, dof, focus; FastDiv div_S, div_spp; };
+struct Cfg {
+    int W, H, S, B;
+    float fov, sky, dof, focus;
+    FastDiv div_S, div_spp;
+    // frame constants of camera-ray generation, computed once on the host with the reference's expressions (World.cpp:70)
+    float one_x, one_y, aspect;
+    float rW, rH, rS, rfocus;   // RN(1/W), RN(1/H), RN(1/S), RN(1/focus): reciprocals for div_by
+    int fast_div;               // the divisions by W, H, S and focus may go through div_by (exact for these operand ranges)
+};
 // which pixels a batch covers: pixels are enumerated tile by tile over the tiles this rank owns
 struct Batch {
     int first_pixel, n_pixels;       // in the rank's pixel enumeration
@@ -105,17 +114,22 @@ __device__ __forceinline__ bool pixel_of(const Batch& bt, int lp, int& px, int& 
 
 // World::CalculateColorForScreenPosition, one sample (World.cpp:70-88)
 __device__ __forceinline__ Ray camera_ray(const Cam& cam, const Cfg& g, int px, int py, int sx, int sy, Rng& rng) {
-    const float one_x = -(1.0f / g.W) * ((float)g.W / g.H) * g.fov, one_y = -(1.0f / g.H) * g.fov;
-    const float off_x = -((float)px / g.W - 0.5f) * ((float)g.W / g.H) * g.fov, off_y = -((float)py / g.H - 0.5f) * g.fov;
+    // quotients by frame constants: the ray's numerators are small integers or lens offsets (0 or at least 2^-36 in
+    // magnitude), inside the range in which div_by reproduces the division exactly
+    const bool fast = g.fast_div != 0;
+    const float fW = (float)g.W, fH = (float)g.H, fS = (float)g.S;
+    const float qx = fast ? div_by((float)px, fW, g.rW) : (float)px / fW, qy = fast ? div_by((float)py, fH, g.rH) : (float)py / fH;
+    const float fx = fast ? div_by((float)sx, fS, g.rS) : (float)sx / fS, fy = fast ? div_by((float)sy, fS, g.rS) : (float)sy / fS;
+    const float off_x = -(qx - 0.5f) * g.aspect * g.fov, off_y = -(qy - 0.5f) * g.fov;
     Ray r;
-    r.d = cam.fwd + (cam.u * (off_x + one_x * ((float)sx / g.S)) + cam.v * (off_y + one_y * ((float)sy / g.S)));
+    r.d = cam.fwd + (cam.u * (off_x + g.one_x * fx) + cam.v * (off_y + g.one_y * fy));
     r.d = normalize(r.d);
     float lx, ly;
     unit_circle_point(rng, lx, ly);
     lx = lx * g.dof; ly = ly * g.dof;
     const V3 wo = cam.u * lx + cam.v * ly;
     r.o = cam.pos + wo;
-    r.d = r.d - divs(wo, g.focus);
+    r.d = r.d - (fast ? mk(div_by(wo.x, g.focus, g.rfocus), div_by(wo.y, g.focus, g.rfocus), div_by(wo.z, g.focus, g.rfocus)) : divs(wo, g.focus));
     r.d = normalize(r.d);
     return r;
 }
@@ -192,6 +206,10 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
                 base = (uint32_t)__shfl((int)base, 0);
                 mine = base < n_in ? base : n_in;
                 mine_end = base + chunk < n_in ? base + chunk : n_in;
+                // guided: the next reservation shrinks with what is left, so that the waves run out of work together
+                const uint32_t left = n_in - mine_end;
+                chunk = (left / (waves * 2u)) & ~63u;
+                chunk = chunk < 64u ? 64u : (chunk > (uint32_t)tune.chunk ? (uint32_t)tune.chunk : chunk);
             }
             if (mine == mine_end) drained = true;
             else {
@@ -422,6 +440,10 @@ __global__ void div_check_kernel(int n, const float* a, const float* b, uint32_t
         if (!mag_in(y, 9.5367431640625e-07f, 1048576.0f)) return;
         if (!(x == 0.0f || mag_in(x, 1.0e-24f, 2.0e12f))) return;
         const float k = 1.0f / y;
+        if (recip_in_range(y) != k) {   // the short reciprocal against the full division
+            if (bad == 0 && atomicAdd(mismatches + 1, 1ull) == 0) { first_bad[0] = 1.0f; first_bad[1] = y; first_bad[2] = recip_in_range(y); first_bad[3] = k; }
+            bad++;
+        }
         const float q1 = div_by(x, y, k), q2 = x / y;
         // a zero quotient may come out with the other sign (a = -0); no comparison of the slab test can tell
         if (!(q1 == q2) && !(q1 != q1 && q2 != q2)) {
@@ -492,8 +514,24 @@ struct rt_engine {
 namespace {
 
 Cfg make_cfg(const rt_config& c) {
-    return Cfg{c.width, c.height, c.samples_per_axis, c.bounces, c.fov, c.skybox_brightness, c.dof_intensity, c.focus_distance,
-               make_fastdiv((uint32_t)c.samples_per_axis), make_fastdiv((uint32_t)(c.samples_per_axis * c.samples_per_axis))};
+    Cfg g{};
+    g.W = c.width; g.H = c.height; g.S = c.samples_per_axis; g.B = c.bounces;
+    g.fov = c.fov; g.sky = c.skybox_brightness; g.dof = c.dof_intensity; g.focus = c.focus_distance;
+    g.div_S = make_fastdiv((uint32_t)c.samples_per_axis);
+    g.div_spp = make_fastdiv((uint32_t)(c.samples_per_axis * c.samples_per_axis));
+    // World.cpp:70: onePixelOffset = (-(1.0f / W) * ((float)W / H) * FOV, -(1.0f / H) * FOV); this file is compiled without
+    // FMA contraction, so the host evaluates them as the reference's build does
+    const float fW = (float)g.W, fH = (float)g.H;
+    g.aspect = fW / fH;
+    g.one_x = -(1.0f / fW) * g.aspect * g.fov;
+    g.one_y = -(1.0f / fH) * g.fov;
+    g.rW = 1.0f / fW; g.rH = 1.0f / fH; g.rS = 1.0f / (float)g.S; g.rfocus = 1.0f / g.focus;
+    const float af = std::fabs(g.focus), ad = std::fabs(g.dof);
+    // div_by is exact for divisors in [2^-20, 2^20] and dividends that are 0 or in [2^-80, 2^40]: pixel and sample
+    // indices are; a lens offset is a sum of two products of dof * (a multiple of 2^-30 below 1) with camera axes
+    g.fast_div = (g.W <= (1 << 20) && g.H <= (1 << 20) && g.S <= (1 << 20) && af >= 9.5367431640625e-07f && af <= 1048576.0f &&
+                  (ad == 0.0f || (ad >= 1.0e-5f && ad <= 1.0e6f))) ? 1 : 0;
+    return g;
 }
 
 void free_scene(rt_engine* e) {
