@@ -346,14 +346,14 @@ struct Walker {
     Closest c;
 };
 // entries (and, when staged, triangles) either in LDS or in global memory
-struct Store { const float4* ent; const float4* tris; const float4* inst; };   // 2 x float4 per entry
+struct Store { const float4* ent; const float4* tris; const float4* inst; const float4* planes; };   // 2 x float4 per entry
 
 __device__ __forceinline__ Ray walker_ray(const Walker& w) {
     Ray r;
     r.o = mk(w.p0.x, w.p0.y, w.p1.x); r.d = mk(w.p3.x, w.p3.y, w.p4.x);
     return r;
 }
-__device__ __forceinline__ void walker_set_ray(Walker& w, const Ray& r, bool scene_ok) {
+__device__ __forceinline__ void walker_set_ray(Walker& w, const Ray r, bool scene_ok) {
     w.usable = scene_ok && ray_usable(r);
     // the reciprocals are only used when the ray is admitted to the reciprocal path, i.e. |d| within [2^-20, 2^20]
     w.p0 = f2{r.o.x, r.o.y}; w.p1 = f2{r.o.z, recip_in_range(r.d.x)}; w.p2 = f2{recip_in_range(r.d.y), recip_in_range(r.d.z)};
@@ -373,7 +373,7 @@ __device__ __forceinline__ void walker_idle(const Scene& sc, Walker& w) {
     w.f0 = 0; w.f1 = 0; w.f2 = 0; w.cnt = 0;
     w.c.dist = FLT_MAX; w.c.best = -1; w.c.u = 0; w.c.v = 0; w.c.hit = false;
 }
-__device__ __forceinline__ void walker_start(const Scene& sc, const Store& st, Walker& w, const Ray& ray) {
+__device__ __forceinline__ void walker_start(const Scene& sc, const Store& st, Walker& w, const Ray ray) {
     walker_set_ray(w, ray, sc.fast_div_ok != 0);
     w.i = 0; w.resume = 0; w.inst = -1; w.stale = sc.stale_entry; w.alpha_off = -1; w.alpha_wh = 0;
     w.f0 = 0; w.f1 = 0; w.f2 = 0; w.cnt = 0;
@@ -686,7 +686,7 @@ __device__ __forceinline__ bool walker_special(const Scene& sc, const Store& st,
         } else {
             const Ray top = walker_ray(w);
             for (int p = 0; p < sc.n_planes; p++) {   // YPlane::Intersect (Object.cpp:139-149), merged as World.cpp:110-118
-                const float t = -(top.o.y - sc.planes[p].x) / top.d.y;
+                const float t = -(top.o.y - st.planes[p].x) / top.d.y;
                 if (t < 0.001f) continue;             // "t < 1e-3" against a double: the same floats pass
                 if (t < w.c.dist) { w.c.hit = true; w.c.dist = t; w.c.best = -(p + 2); }
             }
@@ -718,6 +718,11 @@ __device__ __forceinline__ bool walker_special(const Scene& sc, const Store& st,
 template <bool LDS>
 __device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Walker& w, int quorum, int prim_quorum, Prof& prof) {
     RT_PROF(unsigned long long t0 = __builtin_readcyclecounter(); prof.rounds++;)
+    // with few rays in the wave (the last rays of a pass) a fixed quorum is never met and every round would advance each
+    // ray by a single step: ask for half of the lanes that hold a ray instead
+    const int busy = __popcll(__ballot(sk_kind(w.sk) != rt::ENT_IDLE));
+    quorum = max(1, min(quorum, (busy + 1) >> 1));
+    prim_quorum = max(1, min(prim_quorum, (busy + 1) >> 1));
     box_steps<LDS>(st, w, quorum, prof);
     RT_PROF(unsigned long long t1 = __builtin_readcyclecounter(); prof.box += t1 - t0;)
     for (;;) {

@@ -39,7 +39,8 @@ constexpr int IBLOCK = 512;         // intersect: 8 waves per block; two blocks 
 constexpr int STILE = 1024;         // shade: queue positions a block handles per round (survivors staged in 32 KiB of LDS)
 // intersect scheduling knobs (defaults in rt_engine_create; RT_REFILL_AT / RT_QUORUM / RT_CHUNK override them for tuning)
 struct Tune {
-    int refill_at;   // a wave fetches new rays once this many lanes are idle
+    int refill_at;   // a wave fetches new rays once this many lanes are idle (pass 0: generating a camera ray is expensive)
+    int refill_at_bounce;   // the same for the bounce passes, where fetching a ray is two loads
     int quorum;      // lanes on inner entries needed to repeat the box-test phase
     int chunk;       // queue positions a wave reserves per atomic (shrunk when a pass holds few rays)
     int prim_quorum; // lanes with an untested leaf needed to repeat the primitive-test phase
@@ -176,9 +177,10 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
         for (int k = threadIdx.x; k < n_ent4; k += blockDim.x) smem[k] = sc.ent[k];
         for (int k = threadIdx.x; k < n_tri4; k += blockDim.x) smem[n_ent4 + k] = sc.tris[k];
         for (int k = threadIdx.x; k < n_inst4; k += blockDim.x) smem[n_ent4 + n_tri4 + k] = sc.inst[k];
+        for (int k = threadIdx.x; k < sc.n_planes; k += blockDim.x) smem[n_ent4 + n_tri4 + n_inst4 + k] = sc.planes[k];
         __syncthreads();
-        st.ent = smem; st.tris = smem + n_ent4; st.inst = smem + n_ent4 + n_tri4;
-    } else { st.ent = sc.ent; st.tris = sc.tris; st.inst = sc.inst; }
+        st.ent = smem; st.tris = smem + n_ent4; st.inst = smem + n_ent4 + n_tri4; st.planes = smem + n_ent4 + n_tri4 + n_inst4;
+    } else { st.ent = sc.ent; st.tris = sc.tris; st.inst = sc.inst; st.planes = sc.planes; }
     const int qin = (pass + 1) & 1;
     const uint32_t n_in = FIRST ? (uint32_t)bt.n_pixels * (uint32_t)(g.S * g.S) : q.counts[pass];
     uint32_t* cursor = &q.cursors[pass];
@@ -199,7 +201,7 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
     for (;;) {
         RT_PROF(const unsigned long long t_r0 = __builtin_readcyclecounter();)
         const unsigned long long idle = __ballot(walker_is_idle(w));
-        if (!drained && __popcll(idle) >= tune.refill_at) {
+        if (!drained && __popcll(idle) >= (FIRST ? tune.refill_at : tune.refill_at_bounce)) {
             if (mine == mine_end) {
                 uint32_t base = 0;
                 if (lane == 0) base = atomicAdd(cursor, chunk);
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(Cfg g, Batch bt, const ui
 __global__ __launch_bounds__(256) void trace_kernel(Scene sc, int n, const float* o3, const float* d3, int32_t* hit_id, float* rec9) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     Store st;
-    st.ent = sc.ent; st.tris = sc.tris; st.inst = sc.inst;
+    st.ent = sc.ent; st.tris = sc.tris; st.inst = sc.inst; st.planes = sc.planes;
     Walker w;
     walker_idle(sc, w);
     Ray r;
@@ -499,7 +501,7 @@ struct rt_engine {
     Debug dbg{nullptr, nullptr, nullptr, nullptr, nullptr};
     bool debug_valid = false;
     int n_cus = 0;
-    Tune tune{32, 8, 512, 16};
+    Tune tune{32, 16, 8, 512, 16};
     int win[4] = {0, 0, 0, 0};          // x0, y0, width, height of the render window
     // statistics of the last render
     std::vector<uint32_t> h_counts;     // per batch: counts (B + 2), cursors (B + 2)
@@ -649,6 +651,7 @@ int rt_engine_create(const rt_config* cfg, rt_engine** out) {
     HIP_TRY(hipMemset(e->dbg.prof, 0, sizeof(unsigned long long) * 16 * 16));
 #endif
     if (const char* v = getenv("RT_REFILL_AT")) e->tune.refill_at = std::max(1, std::min(64, atoi(v)));
+    if (const char* v = getenv("RT_REFILL_AT_BOUNCE")) e->tune.refill_at_bounce = std::max(1, std::min(64, atoi(v)));
     if (const char* v = getenv("RT_QUORUM")) e->tune.quorum = std::max(1, std::min(65, atoi(v)));
     if (const char* v = getenv("RT_CHUNK")) e->tune.chunk = std::max(64, atoi(v) & ~63);
     if (const char* v = getenv("RT_PRIM_QUORUM")) e->tune.prim_quorum = std::max(1, std::min(65, atoi(v)));
@@ -769,7 +772,7 @@ int rt_engine_set_scene(rt_engine* e, const rt_scene* s) {
     sc.idle_entry = f->idle_entry;
     e->sc = sc;
     // stage the whole scene in LDS when two 1024-thread blocks per CU can each hold it (160 KiB per CU)
-    const size_t need = (inter.size() + f->tris.size() + f->inst.size()) * 16;
+    const size_t need = (inter.size() + f->tris.size() + f->inst.size() + f->planes.size()) * 16;
     e->staged_bytes = need <= 80 * 1024 ? need : 0;
     if (e->staged_bytes) {
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->staged_bytes));
