@@ -44,6 +44,7 @@ struct Tune {
     int quorum;      // lanes on inner entries needed to repeat the box-test phase
     int chunk;       // queue positions a wave reserves per atomic (shrunk when a pass holds few rays)
     int prim_quorum; // lanes with an untested leaf needed to repeat the primitive-test phase
+    int min_chunk;      // smallest reservation (64 to 128 is best: thinner spreading leaves lanes idle, thicker starves waves)
 };
 
 // Division of a 32-bit unsigned number by a divisor fixed for the whole launch: n / d = (((n - q) >> 1) + q) >> shift with
@@ -167,12 +168,12 @@ __device__ __forceinline__ bool fetch_ray(const Cam& cam, const Cfg& g, const Ba
     return true;
 }
 
-// ---- intersect (World.cpp:105-119) ----------------------------------------------------------------------------------
-template <bool FIRST, bool STAGED>
-__global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cfg g, Batch bt, Queues q, int pass, Debug dbg, Tune tune) {
-    extern __shared__ float4 smem[];
+// Where the traversal reads the scene from: the block's own copy in LDS (entries, triangles, instance and plane records,
+// copied once; blocks are persistent), or global memory when the scene is too large for that.
+template <bool STAGED>
+__device__ __forceinline__ Store stage_scene(const Scene& sc, float4* smem) {
     Store st;
-    if (STAGED) {   // whole scene (entries + triangles) into LDS once per block; blocks are persistent
+    if (STAGED) {
         const int n_ent4 = 2 * sc.n_entries, n_tri4 = rt::RT_TRI_F4 * sc.n_tris, n_inst4 = rt::RT_INST_F4 * sc.n_inst;
         for (int k = threadIdx.x; k < n_ent4; k += blockDim.x) smem[k] = sc.ent[k];
         for (int k = threadIdx.x; k < n_tri4; k += blockDim.x) smem[n_ent4 + k] = sc.tris[k];
@@ -181,6 +182,14 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
         __syncthreads();
         st.ent = smem; st.tris = smem + n_ent4; st.inst = smem + n_ent4 + n_tri4; st.planes = smem + n_ent4 + n_tri4 + n_inst4;
     } else { st.ent = sc.ent; st.tris = sc.tris; st.inst = sc.inst; st.planes = sc.planes; }
+    return st;
+}
+
+// ---- intersect (World.cpp:105-119) ----------------------------------------------------------------------------------
+template <bool FIRST, bool STAGED>
+__global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cfg g, Batch bt, Queues q, int pass, Debug dbg, Tune tune) {
+    extern __shared__ float4 smem[];
+    const Store st = stage_scene<STAGED>(sc, smem);
     const int qin = (pass + 1) & 1;
     const uint32_t n_in = FIRST ? (uint32_t)bt.n_pixels * (uint32_t)(g.S * g.S) : q.counts[pass];
     uint32_t* cursor = &q.cursors[pass];
@@ -193,8 +202,8 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
     uint32_t mine = 0, mine_end = 0;
     // few rays in the pass: smaller reservations, so that every wave of the grid gets some
     const uint32_t waves = gridDim.x * (IBLOCK / 64);
-    uint32_t chunk = (n_in / (waves * 2u)) & ~63u;
-    chunk = chunk < 64u ? 64u : (chunk > (uint32_t)tune.chunk ? (uint32_t)tune.chunk : chunk);
+    uint32_t chunk = (n_in / (waves * 2u)) & ~7u;
+    chunk = chunk < (uint32_t)tune.min_chunk ? (uint32_t)tune.min_chunk : (chunk > (uint32_t)tune.chunk ? (uint32_t)tune.chunk : chunk);
     bool drained = false;   // wave-uniform: every queue position has been handed out
     Prof prof;
     RT_PROF(const unsigned long long t_start = __builtin_readcyclecounter(); unsigned n_refills = 0;)
@@ -210,8 +219,8 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
                 mine_end = base + chunk < n_in ? base + chunk : n_in;
                 // guided: the next reservation shrinks with what is left, so that the waves run out of work together
                 const uint32_t left = n_in - mine_end;
-                chunk = (left / (waves * 2u)) & ~63u;
-                chunk = chunk < 64u ? 64u : (chunk > (uint32_t)tune.chunk ? (uint32_t)tune.chunk : chunk);
+                chunk = (left / (waves * 2u)) & ~7u;
+                chunk = chunk < (uint32_t)tune.min_chunk ? (uint32_t)tune.min_chunk : (chunk > (uint32_t)tune.chunk ? (uint32_t)tune.chunk : chunk);
             }
             if (mine == mine_end) drained = true;
             else {
@@ -249,6 +258,52 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
 #endif
 }
 
+// ---- one bounce of World::GetRayColor (World.cpp:121-170) for a ray whose closest hit is known.  Returns true when the
+// path goes on: `next` is the bounce ray, the (factor, texture colour) of this bounce is on the path's colour stack.
+// Otherwise the path ends here: the stack is unwound and the sample's radiance stored.
+template <bool FIRST>
+__device__ __forceinline__ bool shade_ray(const Scene& sc, const Cfg& g, const Queues& q, const Debug& dbg, const Ray& ray, Rng& rng,
+                                          uint32_t slot, uint32_t depth, const Closest& c, Ray& next) {
+    bool alive = false;
+    Hit h;
+    if (c.hit) finalize_hit(sc, ray, c, h);
+    if (FIRST) {
+        if (dbg.primary_t) dbg.primary_t[slot] = c.dist;
+        if (dbg.primary_id) dbg.primary_id[slot] = c.hit ? h.object : -1;
+    }
+    V3 L = mk(0, 0, 0);
+    if (!c.hit) L = skybox_pixel(sc, ray.d) * g.sky;
+    else {
+        const float4* ob = sc.objects + (size_t)h.object * rt::RT_OBJ_F4;
+        const int mtype = __float_as_int(ob[0].x);
+        const int remaining = g.B - (int)depth;       // the recursion's bounceAmount
+        if (mtype == RT_MAT_LIGHT) L = xyz(ob[3]);
+        else if (mtype != RT_MAT_NONE && remaining != 0) {
+            float factor = 1.0f;
+            next.o = h.point;
+            if (mtype == RT_MAT_DIFFUSE) {
+                next.d = normalize(h.normal + unit_sphere_point(rng));
+                factor = 0.5f;                        // lightDarknerFactor (World.cpp:129)
+            } else if (mtype == RT_MAT_METAL) {
+                next.d = normalize(ray.d - (h.normal * 2.0f) * dot(ray.d, h.normal));
+            } else next.d = unit_sphere_point(rng);    // Isotropic (World.cpp:163)
+            const V3 tex = texture_color(sc, ob, h);
+            q.stack[(size_t)depth * q.capacity + slot] = make_float4(tex.x, tex.y, tex.z, factor);
+            alive = true;
+        }
+    }
+    if (!alive) {
+        // unwind the recursion: colour = (factor * child) * texture, innermost first (World.cpp:138,151,166)
+        for (int k = (int)depth - 1; k >= 0; k--) {
+            const float4 sk = q.stack[(size_t)k * q.capacity + slot];
+            L = (L * sk.w) * mk(sk.x, sk.y, sk.z);
+        }
+        q.radiance[slot] = make_float4(L.x, L.y, L.z, 0.0f);
+        if (dbg.rng_draws) dbg.rng_draws[slot] = rng.ctr;
+    }
+    return alive;
+}
+
 // ---- shade + compact (World.cpp:121-170) ------------------------------------------------------------------------------
 template <bool FIRST>
 __global__ __launch_bounds__(256) void shade_kernel(Scene sc, Cam cam, Cfg g, Batch bt, Queues q, int pass, Debug dbg) {
@@ -276,42 +331,7 @@ __global__ __launch_bounds__(256) void shade_kernel(Scene sc, Cam cam, Cfg g, Ba
             const float4 hr = q.hit[i];
             Closest c;
             c.dist = hr.x; c.best = __float_as_int(hr.y); c.u = hr.z; c.v = hr.w; c.hit = c.best != -1;
-            Hit h;
-            if (c.hit) finalize_hit(sc, ray, c, h);
-            if (FIRST) {
-                if (dbg.primary_t) dbg.primary_t[slot] = c.dist;
-                if (dbg.primary_id) dbg.primary_id[slot] = c.hit ? h.object : -1;
-            }
-            V3 L = mk(0, 0, 0);
-            if (!c.hit) L = skybox_pixel(sc, ray.d) * g.sky;
-            else {
-                const float4* ob = sc.objects + (size_t)h.object * rt::RT_OBJ_F4;
-                const int mtype = __float_as_int(ob[0].x);
-                const int remaining = g.B - (int)depth;       // the recursion's bounceAmount
-                if (mtype == RT_MAT_LIGHT) L = xyz(ob[3]);
-                else if (mtype != RT_MAT_NONE && remaining != 0) {
-                    float factor = 1.0f;
-                    next.o = h.point;
-                    if (mtype == RT_MAT_DIFFUSE) {
-                        next.d = normalize(h.normal + unit_sphere_point(rng));
-                        factor = 0.5f;                        // lightDarknerFactor (World.cpp:129)
-                    } else if (mtype == RT_MAT_METAL) {
-                        next.d = normalize(ray.d - (h.normal * 2.0f) * dot(ray.d, h.normal));
-                    } else next.d = unit_sphere_point(rng);    // Isotropic (World.cpp:163)
-                    const V3 tex = texture_color(sc, ob, h);
-                    q.stack[(size_t)depth * q.capacity + slot] = make_float4(tex.x, tex.y, tex.z, factor);
-                    alive = true;
-                }
-            }
-            if (!alive) {
-                // unwind the recursion: colour = (factor * child) * texture, innermost first (World.cpp:138,151,166)
-                for (int k = (int)depth - 1; k >= 0; k--) {
-                    const float4 sk = q.stack[(size_t)k * q.capacity + slot];
-                    L = (L * sk.w) * mk(sk.x, sk.y, sk.z);
-                }
-                q.radiance[slot] = make_float4(L.x, L.y, L.z, 0.0f);
-                if (dbg.rng_draws) dbg.rng_draws[slot] = rng.ctr;
-            }
+            alive = shade_ray<FIRST>(sc, g, q, dbg, ray, rng, slot, depth, c, next);
         }
         // compact: survivors of this wave (ballot + prefix count) take consecutive places in the block's staging tile
         const unsigned long long mask = __ballot(alive);
@@ -501,7 +521,7 @@ struct rt_engine {
     Debug dbg{nullptr, nullptr, nullptr, nullptr, nullptr};
     bool debug_valid = false;
     int n_cus = 0;
-    Tune tune{32, 16, 8, 512, 16};
+    Tune tune{32, 16, 8, 512, 16, 64};
     int win[4] = {0, 0, 0, 0};          // x0, y0, width, height of the render window
     // statistics of the last render
     std::vector<uint32_t> h_counts;     // per batch: counts (B + 2), cursors (B + 2)
@@ -654,6 +674,7 @@ int rt_engine_create(const rt_config* cfg, rt_engine** out) {
     if (const char* v = getenv("RT_REFILL_AT_BOUNCE")) e->tune.refill_at_bounce = std::max(1, std::min(64, atoi(v)));
     if (const char* v = getenv("RT_QUORUM")) e->tune.quorum = std::max(1, std::min(65, atoi(v)));
     if (const char* v = getenv("RT_CHUNK")) e->tune.chunk = std::max(64, atoi(v) & ~63);
+    if (const char* v = getenv("RT_MIN_CHUNK")) e->tune.min_chunk = std::max(8, atoi(v) & ~7);
     if (const char* v = getenv("RT_PRIM_QUORUM")) e->tune.prim_quorum = std::max(1, std::min(65, atoi(v)));
     *out = e;
     return RT_OK;
