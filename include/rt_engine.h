@@ -47,9 +47,8 @@ typedef struct rt_config {
     int32_t device;                  /* HIP device ordinal                                           */
     int32_t max_batch_paths;         /* ray-queue capacity in paths (pixel samples) per batch; 0 = default */
     int32_t tile_w, tile_h;          /* image-space tile used to split a frame across GPUs; 0 = 64      */
-    int32_t flags;                   /* RT_FLAG_* */
+    int32_t flags;                   /* reserved, 0 */
 } rt_config;
-#define RT_FLAG_COUNT_STATS 1        /* count rays / bounces on the device (rt_get_stats) */
 void rt_config_defaults(rt_config* cfg);   /* the values of Constants.h:4-17 */
 
 /* ---------------------------------------------------------------------------------------------------------
@@ -78,6 +77,11 @@ int rt_scene_add_mesh(rt_scene* s, const float* verts8, int n_tri, float size, i
                       int rot_axis, float degrees, int has_move, const float offset[3]);
 int rt_scene_add_mesh_file(rt_scene* s, const char* obj_path, float size, int material,
                            int rot_axis, float degrees, int has_move, const float offset[3]);
+/* Fog (Object.h:48-57, Object.cpp:558-599): a constant-density volume in the cube centre +- radius; `material` must be
+ * Isotropic (the reference's Fog makes its own from a texture).  Optional rotation / movement wrappers as for meshes
+ * (World.cpp:40: ApplyXRotation(20, Fog(...))). */
+int rt_scene_add_fog(rt_scene* s, const float center[3], float radius, float density, int material,
+                     int rot_axis, float degrees, int has_move, const float offset[3]);
 /* Skybox (DataUtility.cpp:17-28): RGB8, flipped rows. */
 int rt_scene_set_skybox(rt_scene* s, const uint8_t* rgb, int w, int h);
 int rt_scene_set_skybox_file(rt_scene* s, const char* png_path);
@@ -155,7 +159,7 @@ int rt_engine_trace(rt_engine* e, int n, const float* origins3, const float* dir
 /* World::GetRayColor (World.cpp:104-171) for arbitrary rays, one RNG key per ray. */
 int rt_engine_ray_color(rt_engine* e, int n, const float* origins3, const float* dirs3, int bounces, const uint32_t* keys, float* rgb3);
 
-/* Counters of the last render (RT_FLAG_COUNT_STATS): paths, rays (closest-hit queries), rays per bounce level [0..32). */
+/* Counters of the last render (always kept: they are the queue counters of the passes): paths, rays (closest-hit queries), rays per bounce level [0..32). */
 typedef struct rt_stats { uint64_t paths, rays; uint64_t rays_at_depth[33]; } rt_stats;
 int rt_engine_get_stats(rt_engine* e, rt_stats* out);
 /* Time of the dominant kernel over the last render, from HIP events recorded on the render stream around every

@@ -392,6 +392,46 @@ def main():
          top_boxes_sha256=np.frombuffer(hashlib.sha256(top3[0].tobytes()).digest(), np.uint8),
          top_left=top3[1], top_right=top3[2], top_leaf_ids=top3[3],
          primary_id=a3["primary_id"].astype(np.int16), primary_t_rows=a3["primary_t"].reshape(216, 384, 4)[::6].copy(), rgba=a3["rgba"])
+    # (c) the reference's alternative scene (World.cpp:34-40, time = 0) plus more fog volumes: Fog draws random numbers
+    # inside the traversal, so the order in which leaves are tested shows up in every path that meets one
+    from raytracer_amd.synthetic import build_from_tables
+    tex_f = [[0, .8, .2, .3, 0, 0, 0], [0, .2, .8, .3, 0, 0, 0], [0, .4, .4, .4, 0, 0, 0], [0, 1, 1, 0, 0, 0, 0], [0, .6, .7, 1, 0, 0, 0],
+             [1, .9, .9, .9, .2, .3, .8]]
+    mat_f = [[1, 0, 0, 0, 0], [1, 1, 0, 0, 0], [1, 2, 0, 0, 0], [4, -1, 5, 2, 2], [3, 3, 0, 0, 0], [3, 4, 0, 0, 0], [2, 5, 0, 0, 0], [1, 5, 0, 0, 0]]
+    obj_f = np.zeros((11, 10), np.float32)
+    obj_f[0] = [1, -6, 0, -6, -5, 6, 6, 0, 0, 0]
+    obj_f[1] = [1, 5, 0, -6, 6, 6, 6, 0, 0, 1]
+    obj_f[2] = [1, -6, 0, 5, 6, 6, 6, 0, 0, 2]
+    obj_f[3] = [1, -6, 5, -6, 6, 6, 6, 0, 0, 2]
+    obj_f[4] = [0, 0, 4.5, 3.5, 2.5, 0, 0, 0, 0, 3]                 # the light, time = 0
+    obj_f[5] = [4, -3, 1, 0, 3.0, 0.5, 0, 20.0, 0, 4]               # ApplyXRotation(20, Fog({-3,1,0}, 3, 0.5, yellow))
+    obj_f[6] = [4, 2.5, 1.5, -2, 1.5, 0.9, -1, 0, 0, 5]             # a plain fog volume
+    obj_f[7] = [4, 1, 3, 1, 1.2, 2.0, 1, 35.0, 1.5, 5]              # Y-rotated and moved
+    obj_f[8] = [0, 3.2, 1.0, 1.0, 1.0, 0, 0, 0, 0, 7]
+    obj_f[9] = [0, -1.0, 0.8, -3.0, 0.8, 0, 0, 0, 0, 6]
+    obj_f[10] = [4, -2, 2, 2.5, 1.0, 4.0, 2, -15.0, 0, 4]           # Z-rotated, dense
+    plane_f = [[0.0, 6]]
+    R.set_custom(w, BUILD_KEY + 3, tex_f, mat_f, obj_f, plane_f)
+    sf = build_from_tables(O.Scene(O.MATH_LIBM), tex_f, mat_f, obj_f, plane_f, sky, BUILD_KEY + 3)
+    topf = R.dump_top(w)
+    for n_, a_, b_ in zip(("boxes", "left", "right", "leaf"), topf, sf.dump_top()):
+        must("fog top " + n_, a_, b_)
+    camf = O.camera(CAM_POS, CAM_LOOK)
+    R.set_camera(w, CAM_POS, CAM_LOOK)
+    Wf, Hf = 240, 135
+    af = R.render(w, Wf, Hf, 2, 6, SEED + 3, threads=8, want=("radiance", "primary_id", "primary_t", "rgba"))
+    bf = sf.render(camf, Wf, Hf, 2, 6, SEED + 3, threads=8, want=("radiance", "primary_id", "primary_t", "rgba"))
+    for k in af:
+        must("fog " + k, af[k], bf[k])
+    fo, fd = special_rays(rng, 3000, box=7.0)
+    fhit, frec = R.trace(w, fo, fd)
+    fh2, fr2 = sf.trace(fo, fd)
+    must("fog trace hit", fhit, fh2)
+    must("fog trace rec", frec[:, :7], fr2[:, :7])
+    save("scene_fog", build_key=np.array(BUILD_KEY + 3, np.uint32), tex=np.array(tex_f, np.float32), mat=np.array(mat_f, np.float32), obj=obj_f,
+         plane=np.array(plane_f, np.float32), cfg=np.array([Wf, Hf, 2, 6]), seed=np.array(SEED + 3), top_left=topf[1], top_right=topf[2],
+         top_leaf_ids=topf[3], primary_id=af["primary_id"].astype(np.int8), primary_t=af["primary_t"], radiance=af["radiance"].astype(np.float32),
+         rgba=af["rgba"], rays_o=fo, rays_d=fd, hit=fhit, rec=frec[:, :7].copy())
     R.free(w)
     print(f"all fixtures written and the oracle restatement matched the reference on every one ({time.time() - t_all:.0f}s)")
 

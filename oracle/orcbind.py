@@ -17,7 +17,7 @@ TEX_COLOR, TEX_CHECKER, TEX_IMAGE = 0, 1, 2
 MAT_NONE, MAT_DIFFUSE, MAT_METAL, MAT_ISOTROPIC, MAT_LIGHT = 0, 1, 2, 3, 4
 MATH_LIBM, MATH_PORTABLE = 0, 1
 COUNTER_NAMES = ("rays", "aabb", "sph_test", "sph_hit", "cube_test", "cube_hit", "plane_test", "plane_hit",
-                 "tri_test", "tri_uv", "inst_enter", "inst_hit", "samples", "shade", "rng")
+                 "tri_test", "tri_uv", "inst_enter", "inst_hit", "samples", "shade", "rng", "fog_test")
 
 
 def _opt(arr):
@@ -49,6 +49,10 @@ def lib():
     L.orc_add_cube_minmax.argtypes = [C.c_void_p, f32p, f32p, C.c_int]
     L.orc_add_cube_center.restype = C.c_int
     L.orc_add_cube_center.argtypes = [C.c_void_p, f32p, C.c_float, C.c_int]
+    L.orc_add_fog.restype = C.c_int
+    L.orc_add_fog.argtypes = [C.c_void_p, f32p, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int, f32p]
+    L.orc_pm_logf.restype = C.c_float
+    L.orc_pm_logf.argtypes = [C.c_float]
     L.orc_add_mesh.restype = C.c_int
     L.orc_add_mesh.argtypes = [C.c_void_p, f32p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int, f32p]
     L.orc_add_plane.restype = C.c_int
@@ -136,6 +140,10 @@ class Scene:
         off = _f3(offset if offset is not None else (0, 0, 0))
         return self.L.orc_add_mesh(self.h, verts8, len(verts8) // 3, size, mat, rot_axis, degrees,
                                    0 if offset is None else 1, off)
+
+    def fog(self, c, radius, density, mat, rot_axis=-1, degrees=0.0, offset=None):
+        off = _f3(offset if offset is not None else (0, 0, 0))
+        return self.L.orc_add_fog(self.h, _f3(c), radius, density, mat, rot_axis, degrees, 0 if offset is None else 1, off)
 
     def plane(self, y, mat):
         return self.L.orc_add_plane(self.h, y, mat)
@@ -248,7 +256,7 @@ class Scene:
         return rgba
 
     def counters(self, reset=False):
-        out = np.zeros(15, np.uint64)
+        out = np.zeros(16, np.uint64)
         self.L.orc_counters(self.h, out, int(reset))
         return dict(zip(COUNTER_NAMES, (int(v) for v in out)))
 

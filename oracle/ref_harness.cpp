@@ -271,6 +271,18 @@ void ref_world_set_custom(void* h, uint32_t build_key, int n_tex, const float* t
         if (kind == 0) made = new Sphere{ glm::vec3{ o[1], o[2], o[3] }, o[4], m };
         else if (kind == 1) made = new AxisAlignedCube{ glm::vec3{ o[1], o[2], o[3] }, glm::vec3{ o[4], o[5], o[6] }, m };
         else if (kind == 2) made = new AxisAlignedCube{ glm::vec3{ o[1], o[2], o[3] }, o[4], m };
+        else if (kind == 4) {   // Fog(pos, radius, density, texture of material), rotation axis o[6] by o[7] degrees, moved by o[8] in x
+            Object* fog = new Fog(glm::vec3{ o[1], o[2], o[3] }, o[4], o[5], m.texture);
+            rw->ids[fog] = i;
+            Object* cur = fog;
+            int axis = (int)o[6];
+            if (axis == 0) cur = new ApplyXRotation(o[7], cur);
+            else if (axis == 1) cur = new ApplyYRotation(o[7], cur);
+            else if (axis == 2) cur = new ApplyZRotation(o[7], cur);
+            rw->ids[cur] = i;
+            if (o[8] != 0.0f) cur = new ApplyMovement({ o[8], 0.0f, 0.0f }, cur);
+            made = cur;
+        }
         else {
             Object* mesh = new PolygonMesh("src/stb_image/tree.obj", o[1], m);
             rw->ids[mesh] = i;
@@ -490,6 +502,7 @@ void ref_trace(void* h, int n, const float* o3, const float* d3, int32_t* hit, f
         Ray r({ o3[3 * i], o3[3 * i + 1], o3[3 * i + 2] }, { d3[3 * i], d3[3 * i + 1], d3[3 * i + 2] });
         HitInfo hi;
         hi.point = glm::vec3(0); hi.normal = glm::vec3(0); hi.uv = glm::vec2(0);
+        ref_rng_set((uint32_t)i, 0);   // Fog tests draw random numbers: one stream per ray
         bool ok = closest_hit(rw->world, r, hi);
         write_hit(ok, hi, object_id(rw, hi.object), hit + i, rec9 + 9 * i);
     }
@@ -538,7 +551,9 @@ void ref_render(void* h, const int* cfg_i, const float* cfg_f, uint32_t seed, in
                 if (ray6) { for (int k = 0; k < 3; k++) { ray6[6 * si + k] = ray.pos[k]; ray6[6 * si + 3 + k] = ray.direction[k]; } }
                 if (primary_id || primary_t) {
                     HitInfo hi;
+                    const uint32_t key_now = g_key, ctr_now = g_ctr;   // a Fog test draws random numbers: probe, then rewind
                     bool ok = closest_hit(w, ray, hi);
+                    ref_rng_set(key_now, ctr_now);
                     if (primary_id) primary_id[si] = ok ? object_id(rw, hi.object) : -1;
                     if (primary_t) primary_t[si] = hi.distance;
                 }

@@ -15,13 +15,14 @@ typedef struct { v3 mn, mx; } Box;
 /* HitInfo (DataUtility.h:52-58); object = index into scene->objs, -1 = nullptr */
 typedef struct { v3 point, normal; int object; float distance; v2 uv; } Hit;
 
-enum { K_SPHERE, K_CUBE, K_PLANE, K_TRI, K_NODE, K_MESH, K_ROT, K_MOVE };
+enum { K_SPHERE, K_CUBE, K_PLANE, K_TRI, K_NODE, K_MESH, K_ROT, K_MOVE, K_FOG };
 enum { C_RAYS, C_AABB, C_SPH_TEST, C_SPH_HIT, C_CUBE_TEST, C_CUBE_HIT, C_PLANE_TEST, C_PLANE_HIT, C_TRI_TEST, C_TRI_UV,
-       C_INST_ENTER, C_INST_HIT, C_SAMPLES, C_SHADE, C_RNG, C_COUNT };
+       C_INST_ENTER, C_INST_HIT, C_SAMPLES, C_SHADE, C_RNG, C_FOG_TEST, C_COUNT };
 
 typedef struct {
     int kind, mat, id;
     v3 c; float r;              /* sphere */
+    float neg_inv_density;      /* fog (its boundary cube is `box`) */
     Box box;                    /* cube extents | node/tri/rotation box */
     float y;                    /* plane */
     v3 p[3]; v2 tc[3]; v3 n[3]; /* triangle vertices */
@@ -146,6 +147,26 @@ float orc_pm_atan2f(float y, float x) {
     return (float)a;
 }
 static float m_sinf(const orc_scene* s, float x) { return s->math_mode == ORC_MATH_PORTABLE ? orc_pm_sinf(x) : sinf(x); }
+/* logf for the fog's free path (Object.cpp:579), evaluated in IEEE double with fdlibm's e_log.c reduction and polynomial
+ * and rounded to float once; the GPU kernels evaluate the same formulas.  x >= 0 (it is a Random01 draw). */
+float orc_pm_logf(float x) {
+    if (x != x) return x;
+    if (x <= 0.0f) return x == 0.0f ? -INFINITY : (x - x) / 0.0f;
+    if (x > FLT_MAX) return x;
+    union { double d; uint64_t u; } v;
+    v.d = (double)x;                                   /* exact; never subnormal as a double */
+    int k = (int)((v.u >> 52) & 0x7FF) - 1023;
+    v.u = (v.u & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;   /* m in [1, 2) */
+    double m = v.d;
+    if (m > 1.41421356237309514547) { m *= 0.5; k += 1; }         /* m in (sqrt(2)/2, sqrt(2)] */
+    const double f = m - 1.0, s = f / (2.0 + f), z = s * s, w = z * z;
+    const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
+    const double t2 = z * (6.666666666666735130e-01 + w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
+    const double R = t2 + t1, hfsq = 0.5 * f * f, dk = (double)k;
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    return (float)(dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f));
+}
+static float m_logf(const orc_scene* s, float x) { return s->math_mode == ORC_MATH_PORTABLE ? orc_pm_logf(x) : logf(x); }
 static float m_atan2f(const orc_scene* s, float y, float x) { return s->math_mode == ORC_MATH_PORTABLE ? orc_pm_atan2f(y, x) : atan2f(y, x); }
 
 /* ------------------------------------------------------------------------------------------------------------
@@ -321,6 +342,33 @@ static int tri_hit(Ctx* c, const Obj* o, int self, const Ray* ray, Hit* hi) {
     return 1;
 }
 
+/* Fog::Intersect (Object.cpp:558-593): a constant-density volume inside an axis-aligned cube.  Draws one Random01 per test
+ * that reaches the free-path computation — inside the traversal, so the order of tests matters. */
+static int fog_hit(Ctx* c, const Obj* o, int self, const Ray* ray, Hit* hi) {
+    c->cnt[C_FOG_TEST]++;
+    Hit info1, info2;
+    memset(&info1, 0, sizeof info1); info1.object = -1; info1.distance = FLT_MAX;
+    info2 = info1;
+    if (!cube_hit(c, o, self, ray, &info1)) return 0;
+    Ray past;
+    past.o = sub3(add3(ray->o, scale3(ray->d, info1.distance)), scale3(info1.normal, 0.001f));
+    past.d = ray->d;
+    const int inside = !cube_hit(c, o, self, &past, &info2);
+    v3 enter, exit_;
+    if (inside) { enter = ray->o; exit_ = past.o; }
+    else { enter = past.o; exit_ = add3(past.o, scale3(past.d, info2.distance)); }
+    const float supposed = o->neg_inv_density * m_logf(c->s, random01(c));
+    const v3 dd = sub3(exit_, enter);                       /* glm::distance(a, b) = length(b - a) */
+    const float travel = sqrtf(dot3(dd, dd));
+    if (supposed > travel) return 0;
+    hi->normal = V3(0, 1, 0);
+    hi->uv.x = 0; hi->uv.y = 0;
+    hi->object = self;
+    hi->distance = supposed;
+    if (!inside) hi->distance += info1.distance;
+    hi->point = add3(ray->o, scale3(scale3(ray->d, hi->distance), 1.001f));
+    return 1;
+}
 static int obj_hit(Ctx* c, int idx, const Ray* ray, Hit* hi);
 
 /* BVH_Node::Intersect (Object.cpp:241-252): the caller's record goes down the left child, a fresh one down the right */
@@ -368,6 +416,7 @@ static int obj_hit(Ctx* c, int idx, const Ray* ray, Hit* hi) {
     case K_CUBE: return cube_hit(c, o, idx, ray, hi);
     case K_PLANE: return plane_hit(c, o, idx, ray, hi);
     case K_TRI: return tri_hit(c, o, idx, ray, hi);
+    case K_FOG: return fog_hit(c, o, idx, ray, hi);
     case K_NODE: return node_hit(c, o, ray, hi);
     case K_MESH:   /* PolygonMesh::Intersect (Object.cpp:490-495) */
         if (obj_hit(c, o->root, ray, hi)) { hi->object = idx; return 1; }
@@ -695,6 +744,34 @@ int orc_add_mesh(orc_scene* s, const float* verts8, int n_tri, float size, int m
     }
     return push_top(s, cur);
 }
+/* Fog (Object.h:48-57) inside optional ApplyX/Y/ZRotation and ApplyMovement wrappers (World.cpp:40).  `mat` must be an
+ * Isotropic material: the reference's Fog builds its own from the texture it is given. */
+int orc_add_fog(orc_scene* s, const float* center, float radius, float density, int mat, int rot_axis, float degrees,
+                int has_move, const float* offset) {
+    int id = s->next_id++;
+    int fi = new_obj(s, K_FOG);
+    Obj* f = &s->objs[fi];
+    f->mat = mat; f->id = id;
+    const v3 c = V3(center[0], center[1], center[2]);
+    f->box.mn = sub3(c, V3(radius, radius, radius));        /* AxisAlignedCube(pos, radius): Object.h:29 */
+    f->box.mx = add3(c, V3(radius, radius, radius));
+    f->neg_inv_density = -1 / density;
+    int cur = fi;
+    if (rot_axis >= 0) {
+        int ri = new_obj(s, K_ROT);
+        Obj* r = &s->objs[ri];
+        r->target = cur; r->axis = rot_axis; r->degrees = degrees; r->id = id;
+        finish_rotation(s, ri);
+        cur = ri;
+    }
+    if (has_move) {
+        int vi = new_obj(s, K_MOVE);
+        Obj* v = &s->objs[vi];
+        v->target = cur; v->offset = V3(offset[0], offset[1], offset[2]); v->id = id;
+        cur = vi;
+    }
+    return push_top(s, cur);
+}
 int orc_add_plane(orc_scene* s, float y, int mat) {
     int i = new_obj(s, K_PLANE);
     Obj* o = &s->objs[i];
@@ -1003,6 +1080,7 @@ void orc_trace(orc_scene* s, int n, const float* o3, const float* d3, int32_t* h
     for (int i = 0; i < n; i++) {
         Ray r; r.o = V3(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]); r.d = V3(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]);
         Hit hi; fresh_hit(&hi);
+        c.key = (uint32_t)i; c.ctr = 0;                 /* fog tests draw random numbers: one stream per ray */
         int ok = closest_hit(&c, &r, &hi);
         hit[i] = ok ? s->objs[hi.object].id : -1;
         float* q = rec9 + 9 * i;

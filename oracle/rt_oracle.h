@@ -35,6 +35,10 @@ int orc_add_cube_center(orc_scene*, const float* c, float half, int mat);
 /* verts: what the reference's OBJ parser yields: n_tri*3 vertices x (pos3, uv2, normal3).  rot_axis -1 = none. */
 int orc_add_mesh(orc_scene*, const float* verts8, int n_tri, float size, int mat, int rot_axis, float degrees,
                  int has_move, const float* offset);
+/* Fog (Object.h:48-57): cube boundary centre +- radius, density; `mat` an Isotropic material; optional rotation /
+ * movement wrappers as for meshes (World.cpp:40) */
+int orc_add_fog(orc_scene*, const float* center, float radius, float density, int mat, int rot_axis, float degrees,
+                int has_move, const float* offset);
 int orc_add_plane(orc_scene*, float y, int mat);
 void orc_set_skybox(orc_scene*, const uint8_t* rgb, int w, int h);
 /* the reference's default scene (World.cpp:15-32); objects get ids 0..17, the plane 18 */
@@ -85,7 +89,8 @@ void orc_render_framemanager(orc_scene*, const int* cfg_i, const float* cfg_f, c
 /* work counters accumulated by orc_render/orc_trace/orc_ray_color since the last reset (15 values):
  * rays, aabb, sph_test, sph_hit, cube_test, cube_hit, plane_test, plane_hit, tri_test, tri_uv, inst_enter, inst_hit,
  * samples, shade, rng */
-void orc_counters(orc_scene*, uint64_t* out15, int reset);
+void orc_counters(orc_scene*, uint64_t* out16, int reset);
+float orc_pm_logf(float x);
 
 /* RNG and portable math, exposed for known-answer tests */
 uint32_t orc_rand31(uint32_t key, uint32_t ctr);

@@ -52,6 +52,7 @@ __device__ __forceinline__ float unit_distance(Rng& g) {
     int r = (int)rand31(g.key, g.ctr++);
     return (float)(r - 1073741823) * 9.31322574615478515625e-10f;
 }
+__device__ __forceinline__ float random01(Rng& g) { return (float)(int)rand31(g.key, g.ctr++) / 2147483648.0f; }   // DataUtility.h:11
 __device__ __forceinline__ V3 unit_sphere_point(Rng& g) {   // DataUtility.h:28-34
     for (;;) {
         V3 s;
@@ -122,6 +123,25 @@ __device__ inline float pm_atan2f(float y, float x) {
     return (float)a;
 }
 
+// logf for the fog's free path (Object.cpp:579): fdlibm's e_log.c reduction and polynomial in IEEE double, rounded to float
+// once; x >= 0 (it is a Random01 draw).  The CPU checker evaluates the same formulas.
+__device__ inline float pm_logf(float x) {
+    if (x != x) return x;
+    if (x <= 0.0f) return x == 0.0f ? -INFINITY : (x - x) / 0.0f;
+    if (x > FLT_MAX) return x;
+    unsigned long long u = (unsigned long long)__double_as_longlong((double)x);
+    int k = (int)((u >> 52) & 0x7FF) - 1023;
+    u = (u & 0x000FFFFFFFFFFFFFull) | 0x3FF0000000000000ull;
+    double m = __longlong_as_double((long long)u);
+    if (m > 1.41421356237309514547) { m *= 0.5; k += 1; }
+    const double f = m - 1.0, s = f / (2.0 + f), z = s * s, w = z * z;
+    const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
+    const double t2 = z * (6.666666666666735130e-01 + w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
+    const double R = t2 + t1, hfsq = 0.5 * f * f, dk = (double)k;
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    return (float)(dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f));
+}
+
 // ---------------------------------------------------------------------------------------------------- scene view
 struct Scene {
     const float4* ent;   // 2 x float4 per entry: lo, hi
@@ -131,6 +151,7 @@ struct Scene {
     uint32_t sky_off, sky_w, sky_h;
     int top_end, stale_entry, n_planes;
     int n_entries, n_tris, n_inst, fast_div_ok, idle_entry;
+    int has_fog;   // some entry is a fog volume: traversal consumes random numbers (Object.cpp:579)
 };
 struct Ray { V3 o, d; };
 
@@ -189,6 +210,25 @@ __device__ __forceinline__ bool cube_test(V3 mn, V3 mx, const Ray& r, float& t, 
     if (tmin < 0) { nmin = nmax; tmin = tmax; }
     t = tmin;
     normal = nmin;
+    return true;
+}
+// Fog::Intersect (Object.cpp:558-593): where the ray would scatter in an unbounded medium of this density, and whether
+// that lies inside the boundary cube.  Draws one Random01 when the ray meets the cube.
+__device__ __forceinline__ bool fog_test(V3 mn, V3 mx, float neg_inv_density, const Ray& r, Rng& rng, float& t) {
+    float t1, t2;
+    V3 n1, n2;
+    if (!cube_test(mn, mx, r, t1, n1)) return false;
+    Ray past;
+    past.o = (r.o + r.d * t1) - n1 * 0.001f;
+    past.d = r.d;
+    const bool inside = !cube_test(mn, mx, past, t2, n2);
+    const V3 enter = inside ? r.o : past.o;
+    const V3 exit_ = inside ? past.o : past.o + past.d * t2;
+    const float supposed = neg_inv_density * pm_logf(random01(rng));
+    const V3 dd = exit_ - enter;
+    const float travel = sqrtf(dot(dd, dd));          // glm::distance
+    if (supposed > travel) return false;
+    t = inside ? supposed : supposed + t1;
     return true;
 }
 // float -> unsigned as the reference's x86-64 build converts it (glm::uvec2 cast, Object.cpp:545): truncate to 64 bits
@@ -343,6 +383,7 @@ struct Walker {
     f2 e01, e23, e45;        // dwords 0..5 of the entry
     uint32_t sk;             // dword 6: kind << 28 | payload; for an inner entry (kind 0) simply the skip index
     uint32_t f0, f1, f2, cnt;   // leaves visited but not yet tested, oldest first, and their number (0..3)
+    Rng rng;                    // the path's random stream: fog volumes draw from it during traversal
     Closest c;
 };
 // entries (and, when staged, triangles) either in LDS or in global memory
@@ -371,9 +412,11 @@ __device__ __forceinline__ void walker_idle(const Scene& sc, Walker& w) {
     w.s0 = w.p0; w.s1 = w.p1; w.s2 = w.p2; w.s3 = w.p3; w.s4 = w.p4; w.s_usable = true;
     w.resume = 0; w.inst = -1; w.stale = -1; w.alpha_off = -1; w.alpha_wh = 0;
     w.f0 = 0; w.f1 = 0; w.f2 = 0; w.cnt = 0;
+    w.rng.key = 0; w.rng.ctr = 0;
     w.c.dist = FLT_MAX; w.c.best = -1; w.c.u = 0; w.c.v = 0; w.c.hit = false;
 }
-__device__ __forceinline__ void walker_start(const Scene& sc, const Store& st, Walker& w, const Ray ray) {
+__device__ __forceinline__ void walker_start(const Scene& sc, const Store& st, Walker& w, const Ray ray, const Rng rng) {
+    w.rng = rng;
     walker_set_ray(w, ray, sc.fast_div_ok != 0);
     w.i = 0; w.resume = 0; w.inst = -1; w.stale = sc.stale_entry; w.alpha_off = -1; w.alpha_wh = 0;
     w.f0 = 0; w.f1 = 0; w.f2 = 0; w.cnt = 0;
@@ -389,7 +432,7 @@ __device__ __forceinline__ void walker_start(const Scene& sc, const Store& st, W
 // One iteration, for the lanes of the wave that can move:
 //   * lanes on an inner entry whose ray is admitted to the reciprocal path: BoundingBox::DoesRayHit
 //     (DataUtility.cpp:35-82), then  i = hit ? i + 1 : skip;
-//   * lanes on a sphere / cube / triangle entry with room in their FIFO: note i, then i = i + 1;
+//   * lanes on a sphere / cube / triangle / fog entry (kinds 1..4) with room in their FIFO: note i, then i = i + 1;
 //   * both: fetch entry i.
 // It repeats while at least `quorum` lanes stand on inner entries (and runs once more for the stragglers).  Lanes on
 // anything else (END, INSTANCE, boxes or rays that need the general test, a full FIFO) wait for the caller.
@@ -447,7 +490,7 @@ __device__ __forceinline__ void box_steps(const Store& st, Walker& w, int quorum
                  "s_and_b64 %[m], vcc, %[usable]\n\t"
                  "v_add_u32_e32 v9, 0xf0000000, %[sk]\n\t"
                  "v_cmp_gt_u32_e64 %[m2], 3, %[cnt]\n\t"
-                 "v_cmp_gt_u32_e32 vcc, 0x30000000, v9\n\t"
+                 "v_cmp_gt_u32_e32 vcc, 0x40000000, v9\n\t"
                  "s_and_b64 %[m2], %[m2], vcc\n\t"
                  "s_or_b64 %[mall], %[m], %[m2]\n\t"
                  "s_cmp_eq_u64 %[mall], 0\n\t"
@@ -550,7 +593,7 @@ __device__ __forceinline__ void box_steps(const Store& st, Walker& w, int quorum
                  "s_and_b64 %[m], vcc, %[usable]\n\t"
                  "v_add_u32_e32 v9, 0xf0000000, %[sk]\n\t"
                  "v_cmp_gt_u32_e64 %[m2], 3, %[cnt]\n\t"
-                 "v_cmp_gt_u32_e32 vcc, 0x30000000, v9\n\t"
+                 "v_cmp_gt_u32_e32 vcc, 0x40000000, v9\n\t"
                  "s_and_b64 %[m2], %[m2], vcc\n\t"
                  "s_or_b64 %[mall], %[m], %[m2]\n\t"
                  "s_cmp_eq_u64 %[mall], 0\n\t"
@@ -663,7 +706,8 @@ __device__ __forceinline__ void prim_step(const Scene& sc, const Store& st, Walk
     else {
         const f2 a = E[0], b = E[1], c = E[2];
         if (kind == rt::ENT_SPHERE) ok = sphere_test(mk(a.x, a.y, b.x), b.y, cur, t, wrote);
-        else { V3 n; ok = cube_test(mk(a.x, a.y, b.x), mk(b.y, c.x, c.y), cur, t, n); }
+        else if (kind == rt::ENT_CUBE) { V3 n; ok = cube_test(mk(a.x, a.y, b.x), mk(b.y, c.x, c.y), cur, t, n); }
+        else ok = fog_test(mk(a.x, a.y, b.x), mk(b.y, c.x, c.y), sc.objects[(size_t)sk_payload(sk) * rt::RT_OBJ_F4].w, cur, w.rng, t);
     }
     // selects rather than branches around the updates: the record stays in registers
     const bool better = ok && (!w.c.hit || t < w.c.dist);
@@ -783,6 +827,19 @@ __device__ inline void finalize_hit(const Scene& sc, const Ray& ray, const Close
         if (n.x == 1 || n.x == -1) { h.u = m01.z; h.v = m01.y; }
         else if (n.y == 1 || n.y == -1) { h.u = m01.x; h.v = m01.z; }
         else { h.u = m01.x; h.v = m01.y; }
+    } else if (kind == rt::ENT_FOG) {   // Object.cpp:585-591, in the frame the volume was tested in
+        const int ii = __float_as_int(eb.w);
+        Ray q = ray;
+        float4 i0, i1, i2;
+        if (ii >= 0) {
+            const float4* I = sc.inst + (size_t)ii * rt::RT_INST_F4;
+            i0 = I[0]; i1 = I[1]; i2 = I[2];
+            q = to_instance(i0, i1, i2, ray);
+        }
+        h.normal = mk(0.0f, 1.0f, 0.0f);
+        h.object = sk_payload(sk);
+        h.point = q.o + (q.d * c.dist) * 1.001f;
+        if (ii >= 0) from_instance(i0, i1, i2, h.point, h.normal);
     } else {   // triangle inside a mesh instance
         const float4* I = sc.inst + (size_t)__float_as_int(eb.w) * rt::RT_INST_F4;
         const float4 i0 = I[0], i1 = I[1], i2 = I[2], i3 = I[3];

@@ -92,6 +92,7 @@ struct Batch {
 struct Queues {
     float4* a[2]; float4* b[2];      // ray records: a = (o.xyz, d.x), b = (d.y, d.z, slot, ctr | depth << 24)
     float4* hit;                     // hit records by queue position: (distance, best entry, u, v)
+    uint32_t* hit_ctr;               // scenes with fog: the path's random-number counter after the traversal
     uint32_t* counts;                // counts[k] = rays entering pass k
     uint32_t* cursors;               // cursors[k] = queue positions of pass k handed out to intersect waves so far
     float4* stack;                   // [depth][slot] = (texture colour rgb, factor)
@@ -140,7 +141,7 @@ __device__ __forceinline__ Ray camera_ray(const Cam& cam, const Cfg& g, int px, 
 // `qin`.  Returns false for a position that holds no ray (a pixel outside the frame in a partial tile).
 template <bool FIRST>
 __device__ __forceinline__ bool fetch_ray(const Cam& cam, const Cfg& g, const Batch& bt, const Queues& q, int qin, const Debug& dbg,
-                                          uint32_t idx, Ray& ray, Rng& rng, uint32_t& slot, uint32_t& depth) {
+                                          uint32_t idx, Ray& ray, Rng& rng, uint32_t& slot, uint32_t& depth, bool need_rng = true) {
     const int spp = g.S * g.S;
     if (FIRST) {
         slot = idx; depth = 0;
@@ -158,7 +159,8 @@ __device__ __forceinline__ bool fetch_ray(const Cam& cam, const Cfg& g, const Ba
     slot = __float_as_uint(b.z);
     const uint32_t cd = __float_as_uint(b.w);
     rng.ctr = cd & 0xFFFFFFu; depth = cd >> 24;
-    if (dbg.keys) rng.key = dbg.keys[slot];
+    if (!need_rng) rng.key = 0;                   // the closest-hit search of a scene without fog draws nothing
+    else if (dbg.keys) rng.key = dbg.keys[slot];
     else {
         const int lp = (int)fdiv(slot, g.div_spp), s = (int)(slot - (uint32_t)lp * (uint32_t)spp);
         int px = 0, py = 0;
@@ -227,9 +229,9 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
                 const uint32_t idx = mine + (uint32_t)__popcll(idle & below);
                 if (walker_is_idle(w) && idx < mine_end) {
                     Ray ray; Rng rng; uint32_t slot, depth;
-                    if (fetch_ray<FIRST>(cam, g, bt, q, qin, dbg, idx, ray, rng, slot, depth)) {
+                    if (fetch_ray<FIRST>(cam, g, bt, q, qin, dbg, idx, ray, rng, slot, depth, sc.has_fog != 0)) {
                         my_idx = idx;
-                        walker_start(sc, st, w, ray);
+                        walker_start(sc, st, w, ray, rng);
                     }
                 }
                 const uint32_t took = (uint32_t)__popcll(idle);
@@ -244,6 +246,7 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
         }
         if (walk_round<STAGED>(sc, st, w, tune.quorum, tune.prim_quorum, prof)) {
             q.hit[my_idx] = make_float4(w.c.dist, __int_as_float(w.c.best), w.c.u, w.c.v);
+            if (sc.has_fog) q.hit_ctr[my_idx] = w.rng.ctr;
         }
     }
 #ifdef RT_PROFILE
@@ -329,6 +332,7 @@ __global__ __launch_bounds__(256) void shade_kernel(Scene sc, Cam cam, Cfg g, Ba
         Ray next = ray;
         if (live) {
             const float4 hr = q.hit[i];
+            if (sc.has_fog) rng.ctr = q.hit_ctr[i];      // fog volumes drew random numbers during the traversal
             Closest c;
             c.dist = hr.x; c.best = __float_as_int(hr.y); c.u = hr.z; c.v = hr.w; c.hit = c.best != -1;
             alive = shade_ray<FIRST>(sc, g, q, dbg, ray, rng, slot, depth, c, next);
@@ -420,7 +424,8 @@ __global__ __launch_bounds__(256) void trace_kernel(Scene sc, int n, const float
     if (i < n) {
         r.o = mk(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]);
         r.d = mk(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]);
-        walker_start(sc, st, w, r);
+        Rng rng; rng.key = (uint32_t)i; rng.ctr = 0;   // fog volumes draw random numbers: one stream per ray
+        walker_start(sc, st, w, r, rng);
     }
     walk_wave_to_end(sc, st, w);
     if (i >= n) return;
@@ -661,6 +666,7 @@ int rt_engine_create(const rt_config* cfg, rt_engine** out) {
         HIP_TRY(hipMalloc((void**)&e->q.b[k], cap * sizeof(float4)));
     }
     HIP_TRY(hipMalloc((void**)&e->q.hit, cap * sizeof(float4)));
+    HIP_TRY(hipMalloc((void**)&e->q.hit_ctr, cap * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&e->q.stack, cap * sizeof(float4) * (size_t)std::max(1, cfg->bounces)));
     HIP_TRY(hipMalloc((void**)&e->q.radiance, cap * sizeof(float4)));
     HIP_TRY(hipMalloc((void**)&e->d_frame, (size_t)cfg->width * cfg->height * 4));
@@ -686,7 +692,7 @@ void rt_engine_destroy(rt_engine* e) {
     (void)hipStreamSynchronize(e->stream);
     free_scene(e);
     for (int k = 0; k < 2; k++) { (void)hipFree(e->q.a[k]); (void)hipFree(e->q.b[k]); }
-    (void)hipFree(e->q.hit);
+    (void)hipFree(e->q.hit); (void)hipFree(e->q.hit_ctr);
     (void)hipFree(e->q.stack); (void)hipFree(e->q.radiance); (void)hipFree(e->d_frame); (void)hipFree(e->d_counts_all);
     (void)hipFree(e->dbg.primary_id); (void)hipFree(e->dbg.primary_t); (void)hipFree(e->dbg.rng_draws);
     for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
@@ -714,6 +720,7 @@ int rt_engine_set_scene(rt_engine* e, const rt_scene* s) {
     // device entries (layout: rt_flat.h), 8 dwords each
     if (f->ent_lo.size() > rt::SK_MASK || f->objects.size() / rt::RT_OBJ_F4 > rt::SK_MASK) return fail(RT_E_INVALID, "scene too large: more than 2^28 entries or objects");
     std::vector<rt::F4> inter(f->ent_lo.size() * 2);
+    bool has_fog = false;
     for (size_t i = 0; i < f->ent_lo.size(); i++) {
         const rt::F4 lo = f->ent_lo[i], hi = f->ent_hi[i];
         const int kind = rt::bits_i(hi.w);
@@ -727,15 +734,18 @@ int rt_engine_set_scene(rt_engine* e, const rt_scene* s) {
             break;
         case rt::ENT_SPHERE: a = lo; b.z = tag(kind, rt::bits_i(hi.x)); break;
         case rt::ENT_CUBE: a = {lo.x, lo.y, lo.z, hi.x}; b = {hi.y, hi.z, tag(kind, rt::bits_i(lo.w)), 0}; break;
+        case rt::ENT_FOG: a = {lo.x, lo.y, lo.z, hi.x}; b = {hi.y, hi.z, tag(kind, rt::bits_i(lo.w)), rt::bits_f(-1)}; has_fog = true; break;
         case rt::ENT_TRI: case rt::ENT_INSTANCE: b.z = tag(kind, rt::bits_i(lo.x)); break;
         default: break;
         }
         inter[2 * i] = a; inter[2 * i + 1] = b;
     }
-    // a triangle entry names the instance it belongs to (every instance has its own range of entries)
+    // a triangle or fog entry names the instance it belongs to (every instance has its own range of entries)
     for (size_t k = 0; k + rt::RT_INST_F4 <= f->inst.size(); k += rt::RT_INST_F4)
-        for (int i = rt::bits_i(f->inst[k + 2].z); i < rt::bits_i(f->inst[k + 2].w); i++)
-            if (rt::bits_i(f->ent_hi[i].w) == rt::ENT_TRI) inter[2 * (size_t)i + 1].w = rt::bits_f((int)(k / rt::RT_INST_F4));
+        for (int i = rt::bits_i(f->inst[k + 2].z); i < rt::bits_i(f->inst[k + 2].w); i++) {
+            const int kind = rt::bits_i(f->ent_hi[i].w);
+            if (kind == rt::ENT_TRI || kind == rt::ENT_FOG) inter[2 * (size_t)i + 1].w = rt::bits_f((int)(k / rt::RT_INST_F4));
+        }
     if (int rc = upload(&ent, inter.data(), inter.size() * 16)) return rc;
     e->scene_allocs.push_back(ent);
     if (int rc = upload(&tris, f->tris.data(), f->tris.size() * 16)) return rc;
@@ -791,6 +801,7 @@ int rt_engine_set_scene(rt_engine* e, const rt_scene* s) {
     sc.top_end = f->top_end; sc.stale_entry = f->stale_entry; sc.n_planes = (int)f->planes.size();
     sc.n_entries = (int)f->ent_lo.size(); sc.n_tris = (int)f->tris.size() / rt::RT_TRI_F4; sc.n_inst = (int)f->inst.size() / rt::RT_INST_F4; sc.fast_div_ok = f->fast_div_ok ? 1 : 0;
     sc.idle_entry = f->idle_entry;
+    sc.has_fog = has_fog ? 1 : 0;
     e->sc = sc;
     // stage the whole scene in LDS when two 1024-thread blocks per CU can each hold it (160 KiB per CU)
     const size_t need = (inter.size() + f->tris.size() + f->inst.size() + f->planes.size()) * 16;

@@ -10,6 +10,7 @@
 //   kind INNER    lo = (min.x, min.y, min.z, skip)        hi = (max.x, max.y, max.z, kind)
 //   kind SPHERE   lo = (c.x, c.y, c.z, radius)            hi = (object id, 0, 0, kind)
 //   kind CUBE     lo = (min.x, min.y, min.z, object id)   hi = (max.x, max.y, max.z, kind)
+//   kind FOG      like CUBE: the volume's boundary; -1 / density is in the object table
 //   kind TRI      lo = (triangle index, 0, 0, 0)          hi = (0, 0, 0, kind)
 //   kind INSTANCE lo = (instance index, 0, 0, 0)          hi = (0, 0, 0, kind)
 //   kind END      closes the top-level list and every instance range; kind IDLE is one extra entry that lanes
@@ -24,6 +25,7 @@
 //                                                 Object.cpp:29-35,156-166): tested by the general slab test
 //   SPHERE     c.x c.y c.z radius 0 0 | kind, object id | 0
 //   CUBE       min.xyz max.xyz | kind, object id | 0
+//   FOG        min.xyz max.xyz | kind, object id | instance the volume belongs to, or -1
 //   TRI        0 0 0 0 0 0 | kind, triangle index | instance the triangle belongs to
 //   INSTANCE   0 0 0 0 0 0 | kind, instance index | 0
 //   END, IDLE  0 ... | kind | 0
@@ -31,7 +33,7 @@
 // Triangle (RT_TRI_F4 = 6 records):  (v0.xyz, -) (v1.xyz, -) (v2.xyz, -) (uv0.xy, uv1.xy) (uv2.xy, n.x, n.y) (n.z, -, -, -)
 // Instance (RT_INST_F4 = 4):         (offset.xyz, has_move) (pivot.xyz, rot axis or -1) (sin, cos, begin, end)
 //                                    (object id, stale entry, word offset of the texture's alpha bit mask or -1, height << 16 | width)   [the last two: device only]
-// Object   (RT_OBJ_F4 = 4):          (material type, texture kind, image index, 0) (colour1.rgb, 0) (colour2.rgb, 0) (emit.rgb, 0)
+// Object   (RT_OBJ_F4 = 4):          (material type, texture kind, image index, -1 / density of a fog volume) (colour1.rgb, 0) (colour2.rgb, 0) (emit.rgb, 0)
 // Plane    (1):                      (y, object id, 0, 0)
 #pragma once
 #include <cstdint>
@@ -41,7 +43,8 @@ namespace rt {
 struct F4 { float x, y, z, w; };
 struct ImageRec { uint32_t offset, w, h, channels; };   // byte offset into the texel pool
 
-enum : int { ENT_INNER = 0, ENT_SPHERE = 1, ENT_CUBE = 2, ENT_TRI = 3, ENT_INSTANCE = 4, ENT_END = 5, ENT_IDLE = 6, ENT_INNER_INV = 7 };
+// kinds 1..4 are the leaves a lane notes and walks past (the traversal loop tests for that range)
+enum : int { ENT_INNER = 0, ENT_SPHERE = 1, ENT_CUBE = 2, ENT_TRI = 3, ENT_FOG = 4, ENT_INSTANCE = 5, ENT_END = 6, ENT_IDLE = 7, ENT_INNER_INV = 8 };
 constexpr int RT_TRI_F4 = 6, RT_INST_F4 = 4, RT_OBJ_F4 = 4;
 constexpr int SK_SHIFT = 28;
 constexpr uint32_t SK_MASK = (1u << SK_SHIFT) - 1u;

@@ -16,13 +16,14 @@ namespace {
 
 thread_local std::string g_error;
 
-enum Kind { SPHERE, CUBE, PLANE, TRI, NODE, MESH, ROT, MOVE };
+enum Kind { SPHERE, CUBE, PLANE, TRI, NODE, MESH, ROT, MOVE, FOG };
 
 struct Obj {
     Kind kind;
     int material = -1, id = -1;
     Vec3 c{0, 0, 0};
     float r = 0;                      // sphere
+    float neg_inv_density = 0;        // fog (its boundary cube is `box`)
     Box3 box{{0, 0, 0}, {0, 0, 0}};   // cube extents; node / triangle / rotation box
     float y = 0;                      // plane
     Vec3 p[3]; Vec2 tc[3]; Vec3 n[3]; // triangle
@@ -197,6 +198,10 @@ struct Flattener {
             f.ent_lo.push_back({o.box.mn.x, o.box.mn.y, o.box.mn.z, bits_f(o.id)});
             f.ent_hi.push_back({o.box.mx.x, o.box.mx.y, o.box.mx.z, bits_f(ENT_CUBE)});
             break;
+        case FOG:    // the boundary cube; the density sits in the object table
+            f.ent_lo.push_back({o.box.mn.x, o.box.mn.y, o.box.mn.z, bits_f(o.id)});
+            f.ent_hi.push_back({o.box.mx.x, o.box.mx.y, o.box.mx.z, bits_f(ENT_FOG)});
+            break;
         case TRI: {
             const int ti = (int)f.tris.size() / RT_TRI_F4;
             f.tris.push_back({o.p[0].x, o.p[0].y, o.p[0].z, 0});
@@ -209,7 +214,7 @@ struct Flattener {
             f.ent_hi.push_back({0, 0, 0, bits_f(ENT_TRI)});
             break;
         }
-        default: {   // MOVE / ROT / MESH chain = one instance
+        default: {   // a MOVE / ROT chain over a mesh or a fog volume = one instance
             (void)top_level;
             f.ent_lo.push_back({bits_f((int)pending.size()), 0, 0, 0});
             f.ent_hi.push_back({0, 0, 0, bits_f(ENT_INSTANCE)});
@@ -226,8 +231,14 @@ struct Flattener {
         f.ent_lo.push_back({o.box.mn.x, o.box.mn.y, o.box.mn.z, 0});
         f.ent_hi.push_back({o.box.mx.x, o.box.mx.y, o.box.mx.z, bits_f(ENT_INNER)});
         emit(o.left, top_level);
-        if (o.right != o.left) emit(o.right, top_level);
+        // a node over a single object has it as both children (Object.cpp:198-200) and tests it twice; for a fog volume
+        // the second test draws a new random number and can hit where the first did not, so it is listed twice
+        if (o.right != o.left || draws_random(o.left)) emit(o.right, top_level);
         f.ent_lo[at].w = bits_f((int)f.ent_lo.size());
+    }
+    bool draws_random(int idx) const {
+        while (s.objs[idx].kind == MOVE || s.objs[idx].kind == ROT) idx = s.objs[idx].target;
+        return s.objs[idx].kind == FOG;
     }
     std::vector<int> pending;   // instance leaves of the top level, in instance-index order
 };
@@ -255,7 +266,8 @@ void flatten(rt_scene& s) {
         }
         const int begin = (int)f.ent_lo.size();
         Flattener sub{s, f};
-        sub.emit(s.objs[idx].root, false);
+        if (s.objs[idx].kind == MESH) sub.emit(s.objs[idx].root, false);
+        else sub.emit_leaf(idx, false);   // a wrapped fog volume: a range of one entry
         const int end = (int)f.ent_lo.size();
         f.ent_lo.push_back({0, 0, 0, 0});
         f.ent_hi.push_back({0, 0, 0, bits_f(ENT_END)});
@@ -291,12 +303,12 @@ void flatten(rt_scene& s) {
     f.texels.resize((f.texels.size() + 15) & ~(size_t)15, 0);
     // objects by id
     f.objects.assign((size_t)s.next_id * RT_OBJ_F4, F4{0, 0, 0, 0});
-    auto put_object = [&](int id, int material) {
+    auto put_object = [&](int id, int material, float neg_inv_density = 0.0f) {
         const Mat& m = s.mats[material];
         int tk = -1, img = -1;
         Vec3 c1{0, 0, 0}, c2{0, 0, 0};
         if (m.tex >= 0) { const Tex& t = s.texs[m.tex]; tk = t.kind; img = t.image; c1 = t.c1; c2 = t.c2; }
-        f.objects[(size_t)id * RT_OBJ_F4 + 0] = {bits_f(m.type), bits_f(tk), bits_f(img), 0};
+        f.objects[(size_t)id * RT_OBJ_F4 + 0] = {bits_f(m.type), bits_f(tk), bits_f(img), neg_inv_density};
         f.objects[(size_t)id * RT_OBJ_F4 + 1] = {c1.x, c1.y, c1.z, 0};
         f.objects[(size_t)id * RT_OBJ_F4 + 2] = {c2.x, c2.y, c2.z, 0};
         f.objects[(size_t)id * RT_OBJ_F4 + 3] = {m.emit.x, m.emit.y, m.emit.z, 0};
@@ -305,7 +317,7 @@ void flatten(rt_scene& s) {
         while (s.objs[idx].kind == MOVE || s.objs[idx].kind == ROT) idx = s.objs[idx].target;
         return idx;
     };
-    for (int idx : s.top) put_object(s.objs[idx].id, s.objs[mesh_of(idx)].material);
+    for (int idx : s.top) put_object(s.objs[idx].id, s.objs[mesh_of(idx)].material, s.objs[mesh_of(idx)].neg_inv_density);
     for (int idx : s.planes) {
         put_object(s.objs[idx].id, s.objs[idx].material);
         f.planes.push_back({s.objs[idx].y, bits_f(s.objs[idx].id), 0, 0});
@@ -442,6 +454,38 @@ int rt_scene_add_mesh(rt_scene* s, const float* verts8, int n_tri, float size, i
     m.kind = MESH; m.material = material; m.id = id; m.size = size;
     m.verts.assign(verts8, verts8 + (size_t)n_tri * 24);
     s->objs.push_back(std::move(m));
+    int cur = (int)s->objs.size() - 1;
+    if (rot_axis >= 0) {
+        Obj r;
+        r.kind = ROT; r.target = cur; r.axis = rot_axis; r.degrees = degrees; r.id = id;
+        s->objs.push_back(r);
+        cur = (int)s->objs.size() - 1;
+    }
+    if (has_move) {
+        Obj v;
+        v.kind = MOVE; v.target = cur; v.id = id;
+        if (offset) v.offset = {offset[0], offset[1], offset[2]};
+        s->objs.push_back(v);
+        cur = (int)s->objs.size() - 1;
+    }
+    s->top.push_back(cur);
+    return id;
+}
+// Fog (Object.h:48-57): boundary AxisAlignedCube(pos, radius) (Object.h:29), negInverseDensity = -1 / density, an
+// Isotropic material of its own built from the texture it is given — here: `material` must be Isotropic.
+int rt_scene_add_fog(rt_scene* s, const float center[3], float radius, float density, int material, int rot_axis, float degrees,
+                     int has_move, const float offset[3]) {
+    if (int rc = check_material(s, material)) return rc;
+    if (!center) return fail(RT_E_INVALID, "null argument");
+    if (s->mats[material].type != RT_MAT_ISOTROPIC) return fail(RT_E_INVALID, "a fog volume needs an isotropic material");
+    if (rot_axis < -1 || rot_axis > 2) return fail(RT_E_INVALID, "rotation axis must be -1, 0, 1 or 2");
+    const int id = s->next_id++;
+    Obj g;
+    g.kind = FOG; g.material = material; g.id = id;
+    const Vec3 c{center[0], center[1], center[2]}, rr{radius, radius, radius};
+    g.box = {c - rr, c + rr};
+    g.neg_inv_density = -1 / density;
+    s->objs.push_back(g);
     int cur = (int)s->objs.size() - 1;
     if (rot_axis >= 0) {
         Obj r;

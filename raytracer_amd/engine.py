@@ -57,6 +57,7 @@ SIGNATURES = {
     "rt_scene_add_cube_minmax": (C.c_int, [_V, f32p, f32p, C.c_int]),
     "rt_scene_add_plane": (C.c_int, [_V, C.c_float, C.c_int]),
     "rt_scene_add_mesh": (C.c_int, [_V, f32p, C.c_int, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int, f32p]),
+    "rt_scene_add_fog": (C.c_int, [_V, f32p, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int, f32p]),
     "rt_scene_add_mesh_file": (C.c_int, [_V, C.c_char_p, C.c_float, C.c_int, C.c_int, C.c_float, C.c_int, f32p]),
     "rt_scene_set_skybox": (C.c_int, [_V, u8p, C.c_int, C.c_int]),
     "rt_scene_set_skybox_file": (C.c_int, [_V, C.c_char_p]),
@@ -221,6 +222,10 @@ class Scene:
         off = _f3(offset if offset is not None else (0, 0, 0))
         return _check(self.L.rt_scene_add_mesh(self.h, verts8, len(verts8) // 3, size, mat, rot_axis, degrees,
                                                0 if offset is None else 1, off))
+
+    def fog(self, c, radius, density, mat, rot_axis=-1, degrees=0.0, offset=None):
+        off = _f3(offset if offset is not None else (0, 0, 0))
+        return _check(self.L.rt_scene_add_fog(self.h, _f3(c), radius, density, mat, rot_axis, degrees, 0 if offset is None else 1, off))
 
     def mesh_file(self, path, size, mat, rot_axis=-1, degrees=0.0, offset=None):
         off = _f3(offset if offset is not None else (0, 0, 0))

@@ -69,6 +69,8 @@ def build_from_tables(S, tex_t, mat_t, obj_t, plane_t, sky, key, verts=None, tex
             S.cube_minmax(row[1:4], row[4:7], m)
         elif k == 2:
             S.cube_center(row[1:4], float(row[4]), m)
+        elif k == 4:    # fog: centre, radius, density, rotation axis (-1 none), degrees, x offset of a movement wrapper (0 none)
+            S.fog(row[1:4], float(row[4]), float(row[5]), m, int(row[6]), float(row[7]), (float(row[8]), 0.0, 0.0) if row[8] != 0 else None)
         else:
             S.mesh(verts, float(row[1]), m, int(row[2]), float(row[3]), row[4:7] if row[7] != 0 else None)
     for p in plane_t:

@@ -413,3 +413,36 @@ def test_grazing_rays_decide_like_the_oracle(rt, orc, golden, assets, oracle_def
     h2, r2 = osc.trace(o, d)
     assert_bits(hit, h2, "synthetic scene, grazing rays: ids")
     assert_bits(rec[:, 0], r2[:, 0], "synthetic scene, grazing rays: distances")
+
+
+def test_fog_scene(rt, orc, golden, assets):
+    """Fog volumes (plain, X/Y/Z-rotated, moved) with the reference's alternative scene around them.  Fog draws random
+    numbers inside the traversal: the engine notes leaves and tests them later, and must still test them in the
+    reference's order, duplicates included.  Bit-exact against the oracle (portable logf); against the reference
+    (libm logf) a free path may round differently, so ids get the same tolerance as colour."""
+    g = golden("scene_fog")
+    args = (g["tex"], g["mat"], g["obj"], g["plane"], None, None, assets["sky"], int(g["build_key"]))
+    scene = build_table_scene(rt.Scene(), *args)
+    osc = build_table_scene(orc.Scene(orc.MATH_PORTABLE), *args)
+    W, H, S, B = (int(v) for v in g["cfg"])
+    cam = rt.camera_look(CAM_POS, CAM_LOOK)
+    e = make_engine(rt, scene, W, H, S, B, cam)
+    e.keep_samples(True)
+    frame = e.render_frame(int(g["seed"]))
+    got = e.read_samples()
+    ref = osc.render(cam, W, H, S, B, int(g["seed"]), threads=8, want=("radiance", "rgba", "rng_draws", "primary_id", "primary_t"))
+    assert_bits(got["primary_id"], ref["primary_id"], "fog scene ids vs the oracle")
+    assert_bits(got["primary_t"], ref["primary_t"], "fog scene distances vs the oracle")
+    assert_bits(got["rng_draws"], ref["rng_draws"], "fog scene RNG draws vs the oracle")
+    assert_bits(got["radiance"], ref["radiance"], "fog scene radiance vs the oracle")
+    assert_bits(frame, ref["rgba"], "fog scene frame vs the oracle")
+    same_ids = float((got["primary_id"].astype(np.int8) == g["primary_id"]).mean())
+    assert same_ids >= 0.9999, f"fog scene ids vs the reference: {same_ids:.6f} identical"
+    assert_frame_close(frame, g["rgba"], "fog scene colour vs the reference")
+    hit, rec = e.trace(g["rays_o"], g["rays_d"])
+    h2, r2 = osc.trace(g["rays_o"], g["rays_d"])
+    assert_bits(hit, h2, "fog scene traced ids vs the oracle")
+    assert_bits(rec[:, :7], r2[:, :7], "fog scene traced records vs the oracle")
+    # batching must not change a fog scene either: the draw counter travels with the hit record
+    e2 = make_engine(rt, scene, W, H, S, B, cam, max_batch_paths=W * S * S * 16)
+    assert_bits(e2.render_frame(int(g["seed"])), frame, "fog scene, batched")

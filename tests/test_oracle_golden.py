@@ -244,3 +244,33 @@ def test_std_sort_restatement_sorts(orc):
     keys = np.concatenate([np.arange(n // 2), np.arange(n // 2)[::-1]]).astype(np.float32)
     order = orc.std_sort(keys)
     assert (np.diff(keys[order]) >= 0).all()
+
+
+def test_fog_scene(orc, golden, assets):
+    """the reference's alternative scene (World.cpp:34-40) plus more fog volumes: Fog::Intersect draws random numbers during
+    the traversal, so ids, distances and radiance only match if every leaf is tested in the reference's order"""
+    g = golden("scene_fog")
+    s = build_table_scene(orc.Scene(orc.MATH_LIBM), g["tex"], g["mat"], g["obj"], g["plane"], None, None, assets["sky"], int(g["build_key"]))
+    top = s.dump_top()
+    assert_bits(top[1], g["top_left"], "fog scene BVH left links")
+    assert_bits(top[2], g["top_right"], "fog scene BVH right links")
+    assert_bits(top[3], g["top_leaf_ids"], "fog scene BVH leaf order")
+    W, H, S, B = (int(v) for v in g["cfg"])
+    out = s.render(orc.camera((0.0, 3.0, -10.0), (0.0, 0.0, 1.0)), W, H, S, B, int(g["seed"]), threads=8)
+    assert_bits(out["primary_id"].astype(np.int8), g["primary_id"], "fog scene ids")
+    assert_bits(out["primary_t"], g["primary_t"], "fog scene distances")
+    assert_bits(out["radiance"], g["radiance"], "fog scene radiance")
+    assert_bits(out["rgba"], g["rgba"], "fog scene frame")
+    hit, rec = s.trace(g["rays_o"], g["rays_d"])
+    assert_bits(hit, g["hit"], "fog scene traced ids")
+    assert_bits(rec[:, :7], g["rec"], "fog scene traced records")
+
+
+def test_portable_logf_is_the_rounded_double_log(orc):
+    import math
+    L = orc.lib()
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([(rng.integers(1, 2 ** 31, 20000) / 2.0 ** 31).astype(np.float32), np.float32([1.0, 0.5, 2.0 ** -31, 3.0])])
+    for x in xs:
+        assert L.orc_pm_logf(float(x)) == np.float32(math.log(float(x)))
+    assert L.orc_pm_logf(0.0) == -np.inf
