@@ -87,6 +87,9 @@ int rt_scene_set_skybox(rt_scene* s, const uint8_t* rgb, int w, int h);
 int rt_scene_set_skybox_file(rt_scene* s, const char* png_path);
 /* The scene of World.cpp:15-32 with assets from asset_dir ("<asset_dir>/src/stb_image/tree.obj" ...). */
 int rt_scene_add_default_objects(rt_scene* s, const char* asset_dir, float time);
+/* The scene of World.cpp:34-40 (the reference's "#else" branch): four slabs, a light that moves with `time`, a fog
+ * volume rotated about X, the plane of World.cpp:17. */
+int rt_scene_add_alt_objects(rt_scene* s, const char* asset_dir, float time);
 /* BVH_Node::BVH_Node (Object.cpp:181-225) for every mesh and for the object list, in the reference's order, with the
  * keyed counter RNG standing in for std::rand; then flattening into the device layout.  Call once. */
 int rt_scene_build(rt_scene* s, uint32_t build_key);

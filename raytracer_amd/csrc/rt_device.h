@@ -693,6 +693,7 @@ __device__ __forceinline__ void box_steps(const Store& st, Walker& w, int quorum
 
 // The oldest noted leaf of the lane: Sphere / AxisAlignedCube / Triangle ::Intersect and the closest-hit bookkeeping of
 // BVH_Node::Intersect (Object.cpp:245-251) and World::GetRayColor (World.cpp:110-118).
+template <bool FOG>
 __device__ __forceinline__ void prim_step(const Scene& sc, const Store& st, Walker& w) {
     const int e = (int)w.f0;
     w.f0 = w.f1; w.f1 = w.f2; w.cnt--;
@@ -707,7 +708,8 @@ __device__ __forceinline__ void prim_step(const Scene& sc, const Store& st, Walk
         const f2 a = E[0], b = E[1], c = E[2];
         if (kind == rt::ENT_SPHERE) ok = sphere_test(mk(a.x, a.y, b.x), b.y, cur, t, wrote);
         else if (kind == rt::ENT_CUBE) { V3 n; ok = cube_test(mk(a.x, a.y, b.x), mk(b.y, c.x, c.y), cur, t, n); }
-        else ok = fog_test(mk(a.x, a.y, b.x), mk(b.y, c.x, c.y), sc.objects[(size_t)sk_payload(sk) * rt::RT_OBJ_F4].w, cur, w.rng, t);
+        else if (FOG) ok = fog_test(mk(a.x, a.y, b.x), mk(b.y, c.x, c.y), sc.objects[(size_t)sk_payload(sk) * rt::RT_OBJ_F4].w, cur, w.rng, t);
+        else ok = false;   // kernels compiled without fog support are only launched for scenes without fog
     }
     // selects rather than branches around the updates: the record stays in registers
     const bool better = ok && (!w.c.hit || t < w.c.dist);
@@ -759,7 +761,7 @@ __device__ __forceinline__ bool walker_special(const Scene& sc, const Store& st,
 }
 // One round for a wave: the traversal loop; then primitive tests, repeated while at least `prim_quorum` lanes have a
 // noted leaf; then the state-changing entries of lanes that have none left.  Returns true in lanes whose ray finished.
-template <bool LDS>
+template <bool LDS, bool FOG>
 __device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Walker& w, int quorum, int prim_quorum, Prof& prof) {
     RT_PROF(unsigned long long t0 = __builtin_readcyclecounter(); prof.rounds++;)
     // with few rays in the wave (the last rays of a pass) a fixed quorum is never met and every round would advance each
@@ -774,7 +776,7 @@ __device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Wal
         const int n = __popcll(__ballot(has));
         if (n == 0) break;
         RT_PROF(prof.prims++; prof.prim_lanes += n;)
-        if (has) prim_step(sc, st, w);
+        if (has) prim_step<FOG>(sc, st, w);
         if (n < prim_quorum) break;
     }
     RT_PROF(unsigned long long t2 = __builtin_readcyclecounter(); prof.prim += t2 - t1;)
@@ -790,7 +792,7 @@ __device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Wal
 // Run the lanes of a wave until all of them have finished.
 __device__ __forceinline__ void walk_wave_to_end(const Scene& sc, const Store& st, Walker& w) {
     Prof prof;
-    while (__any(sk_kind(w.sk) != rt::ENT_IDLE)) walk_round<false>(sc, st, w, 24, 32, prof);
+    while (__any(sk_kind(w.sk) != rt::ENT_IDLE)) walk_round<false, true>(sc, st, w, 24, 32, prof);
 }
 __device__ __forceinline__ bool walker_is_idle(const Walker& w) { return sk_kind(w.sk) == rt::ENT_IDLE; }
 

@@ -188,7 +188,7 @@ __device__ __forceinline__ Store stage_scene(const Scene& sc, float4* smem) {
 }
 
 // ---- intersect (World.cpp:105-119) ----------------------------------------------------------------------------------
-template <bool FIRST, bool STAGED>
+template <bool FIRST, bool STAGED, bool FOG>
 __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cfg g, Batch bt, Queues q, int pass, Debug dbg, Tune tune) {
     extern __shared__ float4 smem[];
     const Store st = stage_scene<STAGED>(sc, smem);
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
                 const uint32_t idx = mine + (uint32_t)__popcll(idle & below);
                 if (walker_is_idle(w) && idx < mine_end) {
                     Ray ray; Rng rng; uint32_t slot, depth;
-                    if (fetch_ray<FIRST>(cam, g, bt, q, qin, dbg, idx, ray, rng, slot, depth, sc.has_fog != 0)) {
+                    if (fetch_ray<FIRST>(cam, g, bt, q, qin, dbg, idx, ray, rng, slot, depth, FOG)) {
                         my_idx = idx;
                         walker_start(sc, st, w, ray, rng);
                     }
@@ -244,9 +244,9 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
             if (drained) break;
             continue;
         }
-        if (walk_round<STAGED>(sc, st, w, tune.quorum, tune.prim_quorum, prof)) {
+        if (walk_round<STAGED, FOG>(sc, st, w, tune.quorum, tune.prim_quorum, prof)) {
             q.hit[my_idx] = make_float4(w.c.dist, __int_as_float(w.c.best), w.c.u, w.c.v);
-            if (sc.has_fog) q.hit_ctr[my_idx] = w.rng.ctr;
+            if (FOG) q.hit_ctr[my_idx] = w.rng.ctr;
         }
     }
 #ifdef RT_PROFILE
@@ -594,10 +594,13 @@ hipEvent_t next_event(rt_engine* e) {
 template <bool FIRST>
 void launch_intersect(rt_engine* e, hipStream_t st, const Cfg& g, const Batch& bt, const Queues& q, int pass) {
     const int blocks = e->n_cus * 2;
-    if (e->staged_bytes)
-        hipLaunchKernelGGL((intersect_kernel<FIRST, true>), dim3(blocks), dim3(IBLOCK), e->staged_bytes, st, e->sc, e->cam, g, bt, q, pass, e->dbg, e->tune);
-    else
-        hipLaunchKernelGGL((intersect_kernel<FIRST, false>), dim3(blocks), dim3(IBLOCK), 0, st, e->sc, e->cam, g, bt, q, pass, e->dbg, e->tune);
+    // the kernel is compiled with and without fog support: a scene without fog pays nothing for it
+    const bool fog = e->sc.has_fog != 0;
+#define RT_LAUNCH_INTERSECT(STAGED, FOG, LDS_BYTES) \
+    hipLaunchKernelGGL((intersect_kernel<FIRST, STAGED, FOG>), dim3(blocks), dim3(IBLOCK), LDS_BYTES, st, e->sc, e->cam, g, bt, q, pass, e->dbg, e->tune)
+    if (e->staged_bytes) { if (fog) RT_LAUNCH_INTERSECT(true, true, e->staged_bytes); else RT_LAUNCH_INTERSECT(true, false, e->staged_bytes); }
+    else { if (fog) RT_LAUNCH_INTERSECT(false, true, 0); else RT_LAUNCH_INTERSECT(false, false, 0); }
+#undef RT_LAUNCH_INTERSECT
 }
 
 // the passes of one batch: pass 0 generates its rays, passes 1..B read the queue the previous pass filled.  counts points
@@ -807,8 +810,10 @@ int rt_engine_set_scene(rt_engine* e, const rt_scene* s) {
     const size_t need = (inter.size() + f->tris.size() + f->inst.size() + f->planes.size()) * 16;
     e->staged_bytes = need <= 80 * 1024 ? need : 0;
     if (e->staged_bytes) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->staged_bytes));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->staged_bytes));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->staged_bytes));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->staged_bytes));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->staged_bytes));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->staged_bytes));
     }
     e->have_scene = true;
     return RT_OK;

@@ -528,6 +528,31 @@ int rt_scene_set_skybox_file(rt_scene* s, const char* path) {
     return rt_scene_set_skybox(s, px.data(), w, h);
 }
 
+// The alternative scene the reference keeps behind "#else" (World.cpp:34-40): a room of four slabs, an emissive sphere that
+// moves with `time`, a fog volume rotated about X, and the checkered metal plane (World.cpp:17).  The light's x is
+// "3 * sin(time * 0.1f)": the unqualified sin takes the double overload, and the product narrows into the vec3.
+int rt_scene_add_alt_objects(rt_scene* s, const char* asset_dir, float time) {
+    if (!s || !asset_dir) return fail(RT_E_INVALID, "null argument");
+    const std::string dir = std::string(asset_dir) + "/src/stb_image/";
+    if (int rc = rt_scene_set_skybox_file(s, (dir + "skybox12.png").c_str())) return rc;   // World.cpp:49
+    auto colored = [&](int type, float r, float g, float b) {
+        const float c[3] = {r, g, b};
+        return rt_scene_add_material(s, type, rt_scene_add_texture_color(s, c), nullptr);
+    };
+    const float slabs[4][6] = {{-6, 0, -6, -5, 6, 6}, {5, 0, -6, 6, 6, 6}, {-6, 0, 5, 6, 6, 6}, {-6, 5, -6, 6, 6, 6}};
+    const float cols[4][3] = {{0.8f, 0.2f, 0.3f}, {0.2f, 0.8f, 0.3f}, {0.4f, 0.4f, 0.4f}, {0.4f, 0.4f, 0.4f}};
+    for (int i = 0; i < 4; i++)
+        rt_scene_add_cube_minmax(s, slabs[i], slabs[i] + 3, colored(RT_MAT_DIFFUSE, cols[i][0], cols[i][1], cols[i][2]));
+    const float light_pos[3] = {(float)(3 * std::sin((double)(time * 0.1f))), 4.5f, 3.5f}, emit[3] = {5.0f, 2.0f, 2.0f};
+    rt_scene_add_sphere(s, light_pos, 2.5f, rt_scene_add_material(s, RT_MAT_LIGHT, -1, emit));
+    const float fog_pos[3] = {-3, 1, 0};
+    const int fog = rt_scene_add_fog(s, fog_pos, 3.0f, 0.5f, colored(RT_MAT_ISOTROPIC, 1.0f, 1.0f, 0.0f), 0, 20.0f, 0, nullptr);
+    if (fog < 0) return fog;
+    const float white[3] = {1.0f, 1.0f, 1.0f}, green[3] = {0.2f, 0.6f, 0.3f};   // World.cpp:17
+    rt_scene_add_plane(s, 0, rt_scene_add_material(s, RT_MAT_METAL, rt_scene_add_texture_checker(s, white, green), nullptr));
+    return RT_OK;
+}
+
 // World.cpp:15-32.  `time` only matters to the alternative scene of World.cpp:34-40, which the reference compiles out.
 int rt_scene_add_default_objects(rt_scene* s, const char* asset_dir, float time) {
     (void)time;

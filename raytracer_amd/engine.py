@@ -62,6 +62,7 @@ SIGNATURES = {
     "rt_scene_set_skybox": (C.c_int, [_V, u8p, C.c_int, C.c_int]),
     "rt_scene_set_skybox_file": (C.c_int, [_V, C.c_char_p]),
     "rt_scene_add_default_objects": (C.c_int, [_V, C.c_char_p, C.c_float]),
+    "rt_scene_add_alt_objects": (C.c_int, [_V, C.c_char_p, C.c_float]),
     "rt_scene_build": (C.c_int, [_V, C.c_uint32]),
     "rt_scene_dump_top": (C.c_int, [_V, C.c_int, f32p, i32p, i32p, i32p, i32p]),
     "rt_scene_dump_mesh": (C.c_int, [_V, C.c_int, C.c_int, f32p, i32p, i32p, C.c_int, f32p, i32p]),
@@ -280,6 +281,13 @@ class Scene:
         out = np.zeros(7, np.int64)
         _check(self.L.rt_scene_flat_info(self.h, out))
         return dict(zip(("entries", "triangles", "instances", "objects", "planes", "texel_bytes", "device_bytes"), (int(v) for v in out)))
+
+
+def alt_scene(build_key, time=0.0, asset_dir=ASSET_DIR):
+    """the scene of World.cpp:34-40: room, moving light, rotated fog volume"""
+    s = Scene()
+    _check(s.L.rt_scene_add_alt_objects(s.h, os.fsencode(asset_dir), time))
+    return s.build(build_key)
 
 
 def default_scene(build_key, asset_dir=ASSET_DIR):

@@ -169,3 +169,18 @@ def test_fog_scene_topology_matches_the_reference(golden, assets):
     with pytest.raises(rt.RtError):
         bad = rt.Scene()
         bad.fog((0, 0, 0), 1.0, 1.0, bad.material(1, bad.texture_color((1, 1, 1)), (0, 0, 0)))   # not an isotropic material
+
+
+def test_alt_scene_is_the_first_six_rows_of_the_fog_fixture(golden, assets):
+    """rt_scene_add_alt_objects builds World.cpp:34-40 at time 0; the fog fixture's first six rows are that scene as given
+    to the reference, so the object records must agree"""
+    import raytracer_amd as rt
+    g = golden("scene_fog")
+    a = rt.alt_scene(123)
+    b = build_table_scene(rt.Scene(), g["tex"], g["mat"], g["obj"][:6], g["plane"], None, None, assets["sky"], 123)
+    assert_bits(a.dump_objects(7)[:6], b.dump_objects(7)[:6], "alternative scene objects")     # the fixture's plane has other colours
+    assert a.dump_objects(7)[6][14:17].tolist() == [np.float32(0.2), np.float32(0.6), np.float32(0.3)]
+    for x, y, n in zip(a.dump_top(), b.dump_top(), ("boxes", "left", "right", "leaf")):
+        assert_bits(x, y, "alternative scene BVH " + n)
+    moved = rt.alt_scene(123, time=7.0)
+    assert moved.dump_objects(7)[4][1] == np.float32(3 * np.sin(np.float64(np.float32(7.0) * np.float32(0.1))))
