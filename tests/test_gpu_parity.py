@@ -446,3 +446,41 @@ def test_fog_scene(rt, orc, golden, assets):
     # batching must not change a fog scene either: the draw counter travels with the hit record
     e2 = make_engine(rt, scene, W, H, S, B, cam, max_batch_paths=W * S * S * 16)
     assert_bits(e2.render_frame(int(g["seed"])), frame, "fog scene, batched")
+
+
+@pytest.mark.parametrize("case", ["single_sphere_no_plane", "single_fog", "one_pixel", "no_bounces", "max_bounces"])
+def test_degenerate_scenes_and_sizes(rt, orc, assets, case):
+    """the small ends of the input space: a BVH whose root has the same object as both children (Object.cpp:198-200), a
+    scene without planes, a 1 x 1 frame, zero bounces, the largest bounce count the engine accepts"""
+    tex = [[0, .7, .6, .5, 0, 0, 0], [1, 1, 1, 1, .1, .4, .2]]
+    mat = [[1, 0, 0, 0, 0], [2, 1, 0, 0, 0], [3, 0, 0, 0, 0]]
+    obj = np.zeros((3, 10), np.float32)
+    obj[0] = [0, 0.5, 2.5, 2.0, 2.0, 0, 0, 0, 0, 0]
+    obj[1] = [1, -4, 0, 1, -2, 3, 4, 0, 0, 0]
+    obj[2] = [4, 2.5, 1.5, -1, 1.5, 0.7, 1, 25.0, 0, 2]
+    plane = [[0.0, 1]]
+    W, H, S, B = 96, 54, 2, 4
+    if case == "single_sphere_no_plane":
+        obj, plane = obj[:1], np.zeros((0, 2), np.float32)
+    elif case == "single_fog":
+        obj = obj[2:]
+    elif case == "one_pixel":
+        W, H = 1, 1
+    elif case == "no_bounces":
+        B = 0
+    elif case == "max_bounces":
+        B, W, H = 32, 48, 27
+    args = (tex, mat, obj, plane, None, None, assets["sky"], 77)
+    scene = build_table_scene(rt.Scene(), *args)
+    osc = build_table_scene(orc.Scene(orc.MATH_PORTABLE), *args)
+    cam = rt.camera_look(CAM_POS, CAM_LOOK)
+    e = make_engine(rt, scene, W, H, S, B, cam)
+    e.keep_samples(True)
+    frame = e.render_frame(9)
+    got = e.read_samples()
+    ref = osc.render(cam, W, H, S, B, 9, threads=4, want=("radiance", "rgba", "rng_draws", "primary_id", "primary_t"))
+    assert_bits(got["primary_id"], ref["primary_id"], case + ": ids")
+    assert_bits(got["primary_t"], ref["primary_t"], case + ": distances")
+    assert_bits(got["rng_draws"], ref["rng_draws"], case + ": RNG draws")
+    assert_bits(got["radiance"], ref["radiance"], case + ": radiance")
+    assert_bits(frame, ref["rgba"], case + ": frame")
