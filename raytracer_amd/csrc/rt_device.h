@@ -707,9 +707,8 @@ __device__ __forceinline__ void prim_step(const Scene& sc, const Store& st, Walk
     else {
         const f2 a = E[0], b = E[1], c = E[2];
         if (kind == rt::ENT_SPHERE) ok = sphere_test(mk(a.x, a.y, b.x), b.y, cur, t, wrote);
-        else if (kind == rt::ENT_CUBE) { V3 n; ok = cube_test(mk(a.x, a.y, b.x), mk(b.y, c.x, c.y), cur, t, n); }
-        else if (FOG) ok = fog_test(mk(a.x, a.y, b.x), mk(b.y, c.x, c.y), sc.objects[(size_t)sk_payload(sk) * rt::RT_OBJ_F4].w, cur, w.rng, t);
-        else ok = false;   // kernels compiled without fog support are only launched for scenes without fog
+        else if (FOG && kind == rt::ENT_FOG) ok = fog_test(mk(a.x, a.y, b.x), mk(b.y, c.x, c.y), sc.objects[(size_t)sk_payload(sk) * rt::RT_OBJ_F4].w, cur, w.rng, t);
+        else { V3 n; ok = cube_test(mk(a.x, a.y, b.x), mk(b.y, c.x, c.y), cur, t, n); }   // kernels without fog support only see scenes without fog
     }
     // selects rather than branches around the updates: the record stays in registers
     const bool better = ok && (!w.c.hit || t < w.c.dist);

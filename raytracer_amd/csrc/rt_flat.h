@@ -44,7 +44,7 @@ struct F4 { float x, y, z, w; };
 struct ImageRec { uint32_t offset, w, h, channels; };   // byte offset into the texel pool
 
 // kinds 1..4 are the leaves a lane notes and walks past (the traversal loop tests for that range)
-enum : int { ENT_INNER = 0, ENT_SPHERE = 1, ENT_CUBE = 2, ENT_TRI = 3, ENT_FOG = 4, ENT_INSTANCE = 5, ENT_END = 6, ENT_IDLE = 7, ENT_INNER_INV = 8 };
+enum : int { ENT_INNER = 0, ENT_SPHERE = 1, ENT_CUBE = 2, ENT_TRI = 3, ENT_FOG = 4, ENT_END = 5, ENT_IDLE = 6, ENT_INNER_INV = 7, ENT_INSTANCE = 8 };
 constexpr int RT_TRI_F4 = 6, RT_INST_F4 = 4, RT_OBJ_F4 = 4;
 constexpr int SK_SHIFT = 28;
 constexpr uint32_t SK_MASK = (1u << SK_SHIFT) - 1u;
