@@ -111,6 +111,28 @@ def cpu_baseline(workload, W, H, S, B, threads):
             "scene_byte_per_ray": nbytes / c["rays"], "rays_per_sample": c["rays"] / c["samples"]}
 
 
+def pmc_traffic(path, kernel):
+    """HBM bytes per frame of one kernel from a summary written by tools/pmc_summary.py (separate rocprofv3 --pmc runs of
+    this same command): FETCH_SIZE and WRITE_SIZE are in units of 1 KiB, and on gfx950 FETCH_SIZE counts half
+    of the bytes read, so  bytes = 1024 * (2 * FETCH_SIZE + WRITE_SIZE), summed over the kernel's template variants."""
+    try:
+        lines = open(path).read().splitlines()
+    except OSError:
+        return None
+    total, inside, seen = 0.0, False, False
+    for ln in lines:
+        if not ln.startswith(" "):
+            inside = ln.startswith(kernel)
+            continue
+        if inside:
+            name, val = ln.split()[:2]
+            if name == "FETCH_SIZE":
+                total += 2048.0 * float(val); seen = True
+            elif name == "WRITE_SIZE":
+                total += 1024.0 * float(val); seen = True
+    return total if seen else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -210,6 +232,13 @@ def main():
         ach_tflops = flop_per_ray * rays_rank0 / kern_s / 1e12 if kern_s > 0 else None
         stream_bytes = HIT_WRITE_BYTES * st["rays"] + RAY_READ_BYTES * (st["rays"] - st["paths"])
         ach_gbs = stream_bytes / kern_s / 1e9 if kern_s > 0 else None
+        # measured HBM traffic of the same kernel: PMC passes cannot run inside this process, so the figure comes from the
+        # committed summary of tools/profile.sh runs of this command (C2, one GPU) and is null for anything else
+        traffic = None
+        if args.workload == "c2" and world == 1 and kern_launches:
+            per_frame = pmc_traffic(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_c2_pmc_summary.txt"),
+                                    "intersect_kernel")
+            traffic = per_frame / kern_launches if per_frame else None
         out = {
             "metric": "Mrays/s", "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -220,7 +249,7 @@ def main():
             "frame_latency_ms": ({"p50": float(np.percentile(frame_ms, 50)), "p99": float(np.percentile(frame_ms, 99)),
                                   "max": float(max(frame_ms))} if frame_ms else None),
             "roofline": {"bound": "valu", "achieved": ach_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (ach_tflops / PEAK_FP32_TFLOPS) if ach_tflops else None, "traffic": None,
+                         "frac": (ach_tflops / PEAK_FP32_TFLOPS) if ach_tflops else None, "traffic": traffic,
                          # the reference's unfused, unpacked arithmetic (kept for bit-exact ids) can issue 1/4 of the peak
                          "frac_of_unfused_peak": (ach_tflops / (PEAK_FP32_TFLOPS / 4)) if ach_tflops else None,
                          "kernel": "intersect_kernel", "launches": kern_launches,
@@ -228,7 +257,9 @@ def main():
                          "flop_per_ray": flop_per_ray, "rays_per_launch": rays_rank0 / kern_launches if kern_launches else None},
             # the same kernel against HBM: ray records in, hit records out (the scene itself is read from LDS)
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                             "frac": (ach_gbs / PEAK_HBM_GBS) if ach_gbs else None, "traffic": None,
+                             "frac": (ach_gbs / PEAK_HBM_GBS) if ach_gbs else None, "traffic": traffic,
+                             "traffic_unit": "bytes per launch (PMC, profiles/r1_c2_pmc_summary.txt)",
+                             "algorithmic_bytes_per_launch": stream_bytes / kern_launches if kern_launches else None,
                              "stream_byte_per_ray": stream_bytes / rays_rank0 if rays_rank0 else None,
                              "scene_byte_per_ray_from_lds": scene_byte_per_ray},
             "cpu_baseline": cpu,
