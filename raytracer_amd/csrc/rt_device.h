@@ -247,11 +247,16 @@ __device__ __forceinline__ int image_index(const rt::ImageRec im, float u, float
 // channel at word alpha_off of Scene::alpha_bits (alpha_wh = height << 16 | width), 32 times smaller than the texels and
 // therefore resident in the vector cache.  `wrote`: HitInfo.distance was assigned although the triangle was rejected
 // by the cut-out.
-__device__ __forceinline__ bool tri_test(const Scene& sc, const float4* tris, int ti, int alpha_off, uint32_t alpha_wh, const Ray& r, float& t, float& uo, float& vo, bool& wrote) {
+//
+// The test is cut in two.  tri_reach is the geometric part (Object.cpp:498-531): does the ray meet the triangle's plane
+// inside the triangle, and at which distance.  tri_surface is everything after it (Object.cpp:532-550): texture
+// coordinates, the cut-out, the assignment of HitInfo.distance.  Most rays that reach a triangle do so behind a hit they
+// already have, where the second part cannot change anything; the traversal runs it only where it can, and for many
+// lanes at once.
+__device__ __forceinline__ bool tri_reach(const float4* tris, int ti, const Ray& r, float& tt) {
     const float EPSILON = 0.0000001f;
     const float4* T = tris + (size_t)ti * rt::RT_TRI_F4;
     const V3 v0 = xyz(T[0]), v1 = xyz(T[1]), v2 = xyz(T[2]);
-    wrote = false;
     const V3 edge1 = v1 - v0, edge2 = v2 - v0;
     const V3 h = cross(r.d, edge2);
     const float a = dot(edge1, h);
@@ -263,10 +268,14 @@ __device__ __forceinline__ bool tri_test(const Scene& sc, const float4* tris, in
     const V3 q = cross(s, edge1);
     const float v = f * dot(r.d, q);
     if (v < 0.0f || u + v > 1.0f) return false;
-    const float tt = f * dot(edge2, q);
-    if (!(tt > EPSILON)) return false;
+    tt = f * dot(edge2, q);
+    return tt > EPSILON;
+}
+__device__ __forceinline__ bool tri_surface(const Scene& sc, const float4* tris, int ti, int alpha_off, uint32_t alpha_wh, const Ray& r, float tt, float& t, float& uo, float& vo, bool& wrote) {
+    const float4* T = tris + (size_t)ti * rt::RT_TRI_F4;
+    const V3 p1 = xyz(T[0]), p2 = xyz(T[1]), p3 = xyz(T[2]);
+    wrote = false;
     const V3 hp = r.o + r.d * tt;
-    const V3 p1 = v0, p2 = v1, p3 = v2;
     const float denominator = p1.y * (p2.z - p3.z) - p2.y * (p1.z - p3.z) + p3.y * (p1.z - p2.z);
     if (denominator == 0) return false;
     t = tt;
@@ -383,6 +392,7 @@ struct Walker {
     f2 e01, e23, e45;        // dwords 0..5 of the entry
     uint32_t sk;             // dword 6: kind << 28 | payload; for an inner entry (kind 0) simply the skip index
     uint32_t f0, f1, f2, cnt;   // leaves visited but not yet tested, oldest first, and their number (0..3)
+    float reach;                // > 0: the ray reaches the triangle f0 at this distance and tri_surface has yet to run
     Rng rng;                    // the path's random stream: fog volumes draw from it during traversal
     Closest c;
 };
@@ -411,7 +421,7 @@ __device__ __forceinline__ void walker_idle(const Scene& sc, Walker& w) {
     w.p0 = f2{0, 0}; w.p1 = f2{0, 1}; w.p2 = f2{1, 1}; w.p3 = f2{1, 1}; w.p4 = f2{1, 0}; w.usable = true;
     w.s0 = w.p0; w.s1 = w.p1; w.s2 = w.p2; w.s3 = w.p3; w.s4 = w.p4; w.s_usable = true;
     w.resume = 0; w.inst = -1; w.stale = -1; w.alpha_off = -1; w.alpha_wh = 0;
-    w.f0 = 0; w.f1 = 0; w.f2 = 0; w.cnt = 0;
+    w.f0 = 0; w.f1 = 0; w.f2 = 0; w.cnt = 0; w.reach = 0.0f;
     w.rng.key = 0; w.rng.ctr = 0;
     w.c.dist = FLT_MAX; w.c.best = -1; w.c.u = 0; w.c.v = 0; w.c.hit = false;
 }
@@ -419,7 +429,7 @@ __device__ __forceinline__ void walker_start(const Scene& sc, const Store& st, W
     w.rng = rng;
     walker_set_ray(w, ray, sc.fast_div_ok != 0);
     w.i = 0; w.resume = 0; w.inst = -1; w.stale = sc.stale_entry; w.alpha_off = -1; w.alpha_wh = 0;
-    w.f0 = 0; w.f1 = 0; w.f2 = 0; w.cnt = 0;
+    w.f0 = 0; w.f1 = 0; w.f2 = 0; w.cnt = 0; w.reach = 0.0f;
     w.c.dist = FLT_MAX; w.c.best = -1; w.c.u = 0; w.c.v = 0; w.c.hit = false;
     walker_load(st, w);
 }
@@ -461,7 +471,7 @@ __device__ __forceinline__ void walker_start(const Scene& sc, const Store& st, W
 // v2..v21 are used as scratch registers by name because the halves of a register pair cannot be named through operands.
 // Every lane of the wave must be enabled at the call.
 // RT_PROFILE builds (make PROF=1) time the phases of every round with the shader clock; see intersect_kernel
-struct Prof { unsigned long long box = 0, prim = 0, special = 0, refill = 0; unsigned rounds = 0, prims = 0, prim_lanes = 0, specials = 0, box_iters = 0, box_lanes = 0; };
+struct Prof { unsigned long long box = 0, prim = 0, special = 0, refill = 0; unsigned rounds = 0, prims = 0, prim_lanes = 0, specials = 0, box_iters = 0, box_lanes = 0, finishes = 0, finish_lanes = 0; };
 #ifdef RT_PROFILE
 #define RT_PROF(x) x
 #else
@@ -692,24 +702,10 @@ __device__ __forceinline__ void box_steps(const Store& st, Walker& w, int quorum
 }
 
 // The oldest noted leaf of the lane: Sphere / AxisAlignedCube / Triangle ::Intersect and the closest-hit bookkeeping of
-// BVH_Node::Intersect (Object.cpp:245-251) and World::GetRayColor (World.cpp:110-118).
-template <bool FOG>
-__device__ __forceinline__ void prim_step(const Scene& sc, const Store& st, Walker& w) {
-    const int e = (int)w.f0;
-    w.f0 = w.f1; w.f1 = w.f2; w.cnt--;
-    const f2* E = reinterpret_cast<const f2*>(st.ent) + 4 * (size_t)e;
-    const uint32_t sk = reinterpret_cast<const uint32_t*>(E)[6];
-    const int kind = sk_kind(sk);
-    const Ray cur = walker_ray(w);
-    float t = 0, u = 0, v = 0;
-    bool ok, wrote = false;
-    if (kind == rt::ENT_TRI) ok = tri_test(sc, st.tris, sk_payload(sk), w.alpha_off, w.alpha_wh, cur, t, u, v, wrote);
-    else {
-        const f2 a = E[0], b = E[1], c = E[2];
-        if (kind == rt::ENT_SPHERE) ok = sphere_test(mk(a.x, a.y, b.x), b.y, cur, t, wrote);
-        else if (FOG && kind == rt::ENT_FOG) ok = fog_test(mk(a.x, a.y, b.x), mk(b.y, c.x, c.y), sc.objects[(size_t)sk_payload(sk) * rt::RT_OBJ_F4].w, cur, w.rng, t);
-        else { V3 n; ok = cube_test(mk(a.x, a.y, b.x), mk(b.y, c.x, c.y), cur, t, n); }   // kernels without fog support only see scenes without fog
-    }
+// BVH_Node::Intersect (Object.cpp:245-251) and World::GetRayColor (World.cpp:110-118).  A triangle the ray reaches stays
+// at the head of the FIFO with its distance in `reach` when the rest of its test can matter — the distance would win, or
+// the leaf is the one whose assignment of HitInfo.distance survives a rejection — and is finished by tri_finish_step.
+__device__ __forceinline__ void closest_update(Walker& w, int e, bool ok, bool wrote, float t, float u, float v) {
     // selects rather than branches around the updates: the record stays in registers
     const bool better = ok && (!w.c.hit || t < w.c.dist);
     const bool stale = !ok && wrote && e == w.stale;
@@ -718,6 +714,39 @@ __device__ __forceinline__ void prim_step(const Scene& sc, const Store& st, Walk
     w.c.u = better ? u : w.c.u;
     w.c.v = better ? v : w.c.v;
     w.c.hit = w.c.hit || better;
+}
+template <bool FOG>
+__device__ __forceinline__ void prim_step(const Scene& sc, const Store& st, Walker& w) {
+    const int e = (int)w.f0;
+    const f2* E = reinterpret_cast<const f2*>(st.ent) + 4 * (size_t)e;
+    const uint32_t sk = reinterpret_cast<const uint32_t*>(E)[6];
+    const int kind = sk_kind(sk);
+    const Ray cur = walker_ray(w);
+    float t = 0;
+    bool ok, wrote = false, wait = false;
+    if (kind == rt::ENT_TRI) {
+        wait = tri_reach(st.tris, sk_payload(sk), cur, t) && (!w.c.hit || t < w.c.dist || e == w.stale);
+        ok = false;
+    } else {
+        const f2 a = E[0], b = E[1], c = E[2];
+        if (kind == rt::ENT_SPHERE) ok = sphere_test(mk(a.x, a.y, b.x), b.y, cur, t, wrote);
+        else if (FOG && kind == rt::ENT_FOG) ok = fog_test(mk(a.x, a.y, b.x), mk(b.y, c.x, c.y), sc.objects[(size_t)sk_payload(sk) * rt::RT_OBJ_F4].w, cur, w.rng, t);
+        else { V3 n; ok = cube_test(mk(a.x, a.y, b.x), mk(b.y, c.x, c.y), cur, t, n); }   // kernels without fog support only see scenes without fog
+    }
+    w.reach = wait ? t : 0.0f;
+    w.f0 = wait ? w.f0 : w.f1; w.f1 = wait ? w.f1 : w.f2; w.cnt -= wait ? 0u : 1u;
+    closest_update(w, e, ok, wrote, t, 0.0f, 0.0f);
+}
+// The second part of Triangle::Intersect for a lane whose head-of-FIFO triangle is waiting for it.
+__device__ __forceinline__ void tri_finish_step(const Scene& sc, const Store& st, Walker& w) {
+    const int e = (int)w.f0;
+    w.f0 = w.f1; w.f1 = w.f2; w.cnt--;
+    const uint32_t sk = reinterpret_cast<const uint32_t*>(st.ent)[8 * (size_t)e + 6];
+    float t = 0, u = 0, v = 0;
+    bool wrote = false;
+    const bool ok = tri_surface(sc, st.tris, sk_payload(sk), w.alpha_off, w.alpha_wh, walker_ray(w), w.reach, t, u, v, wrote);
+    w.reach = 0.0f;
+    closest_update(w, e, ok, wrote, t, u, v);
 }
 // Entries that change the lane's state beyond its position; they wait until every noted leaf has been tested.  Returns
 // true when the ray has finished (closest hit known, plane list merged); the lane is idle from then on.
@@ -761,22 +790,33 @@ __device__ __forceinline__ bool walker_special(const Scene& sc, const Store& st,
 // One round for a wave: the traversal loop; then primitive tests, repeated while at least `prim_quorum` lanes have a
 // noted leaf; then the state-changing entries of lanes that have none left.  Returns true in lanes whose ray finished.
 template <bool LDS, bool FOG>
-__device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Walker& w, int quorum, int prim_quorum, Prof& prof) {
+__device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Walker& w, int quorum, int prim_quorum, int finish_quorum, Prof& prof) {
     RT_PROF(unsigned long long t0 = __builtin_readcyclecounter(); prof.rounds++;)
     // with few rays in the wave (the last rays of a pass) a fixed quorum is never met and every round would advance each
     // ray by a single step: ask for half of the lanes that hold a ray instead
     const int busy = __popcll(__ballot(sk_kind(w.sk) != rt::ENT_IDLE));
     quorum = max(1, min(quorum, (busy + 1) >> 1));
     prim_quorum = max(1, min(prim_quorum, (busy + 1) >> 1));
+    finish_quorum = max(1, min(finish_quorum, (busy + 1) >> 1));
     box_steps<LDS>(st, w, quorum, prof);
     RT_PROF(unsigned long long t1 = __builtin_readcyclecounter(); prof.box += t1 - t0;)
     for (;;) {
-        const bool has = w.cnt != 0;
+        const bool has = w.cnt != 0 && w.reach == 0.0f;
         const int n = __popcll(__ballot(has));
         if (n == 0) break;
         RT_PROF(prof.prims++; prof.prim_lanes += n;)
         if (has) prim_step<FOG>(sc, st, w);
         if (n < prim_quorum) break;
+    }
+    // triangles waiting for the second part of their test: run it once enough lanes have one (a waiting lane goes on
+    // walking and noting leaves meanwhile, but tests no further primitive, so the order of the updates is the reference's)
+    {
+        const bool waiting = w.reach != 0.0f;
+        const int n = __popcll(__ballot(waiting));
+        if (n >= finish_quorum) {
+            RT_PROF(prof.finishes++; prof.finish_lanes += n;)
+            if (waiting) tri_finish_step(sc, st, w);
+        }
     }
     RT_PROF(unsigned long long t2 = __builtin_readcyclecounter(); prof.prim += t2 - t1;)
     const int kind = sk_kind(w.sk);
@@ -791,7 +831,7 @@ __device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Wal
 // Run the lanes of a wave until all of them have finished.
 __device__ __forceinline__ void walk_wave_to_end(const Scene& sc, const Store& st, Walker& w) {
     Prof prof;
-    while (__any(sk_kind(w.sk) != rt::ENT_IDLE)) walk_round<false, true>(sc, st, w, 24, 32, prof);
+    while (__any(sk_kind(w.sk) != rt::ENT_IDLE)) walk_round<false, true>(sc, st, w, 24, 32, 16, prof);
 }
 __device__ __forceinline__ bool walker_is_idle(const Walker& w) { return sk_kind(w.sk) == rt::ENT_IDLE; }
 

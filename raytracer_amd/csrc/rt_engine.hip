@@ -45,6 +45,8 @@ struct Tune {
     int chunk;       // queue positions a wave reserves per atomic (shrunk when a pass holds few rays)
     int prim_quorum; // lanes with an untested leaf needed to repeat the primitive-test phase
     int min_chunk;      // smallest reservation (64 to 128 is best: thinner spreading leaves lanes idle, thicker starves waves)
+    int finish_quorum;  // lanes whose triangle waits for the second part of its test needed to run that part (1 measured best:
+                        // a waiting lane tests no further leaf, and that costs more than running the part for few lanes)
 };
 
 // Division of a 32-bit unsigned number by a divisor fixed for the whole launch: n / d = (((n - q) >> 1) + q) >> shift with
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
             if (drained) break;
             continue;
         }
-        if (walk_round<STAGED, FOG>(sc, st, w, tune.quorum, tune.prim_quorum, prof)) {
+        if (walk_round<STAGED, FOG>(sc, st, w, tune.quorum, tune.prim_quorum, tune.finish_quorum, prof)) {
             q.hit[my_idx] = make_float4(w.c.dist, __int_as_float(w.c.best), w.c.u, w.c.v);
             if (FOG) q.hit_ctr[my_idx] = w.rng.ctr;
         }
@@ -257,6 +259,7 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
         atomicAdd(p + 7, (unsigned long long)prof.prims); atomicAdd(p + 8, (unsigned long long)prof.prim_lanes);
         atomicAdd(p + 9, (unsigned long long)prof.specials); atomicAdd(p + 10, (unsigned long long)n_refills);
         atomicAdd(p + 11, (unsigned long long)prof.box_iters); atomicAdd(p + 12, (unsigned long long)prof.box_lanes);
+        atomicAdd(p + 13, (unsigned long long)prof.finishes); atomicAdd(p + 14, (unsigned long long)prof.finish_lanes);
     }
 #endif
 }
@@ -526,7 +529,7 @@ struct rt_engine {
     Debug dbg{nullptr, nullptr, nullptr, nullptr, nullptr};
     bool debug_valid = false;
     int n_cus = 0;
-    Tune tune{32, 16, 8, 512, 16, 64};
+    Tune tune{32, 16, 8, 512, 16, 64, 1};
     int win[4] = {0, 0, 0, 0};          // x0, y0, width, height of the render window
     // statistics of the last render
     std::vector<uint32_t> h_counts;     // per batch: counts (B + 2), cursors (B + 2)
@@ -684,6 +687,7 @@ int rt_engine_create(const rt_config* cfg, rt_engine** out) {
     if (const char* v = getenv("RT_QUORUM")) e->tune.quorum = std::max(1, std::min(65, atoi(v)));
     if (const char* v = getenv("RT_CHUNK")) e->tune.chunk = std::max(64, atoi(v) & ~63);
     if (const char* v = getenv("RT_MIN_CHUNK")) e->tune.min_chunk = std::max(8, atoi(v) & ~7);
+    if (const char* v = getenv("RT_FINISH_QUORUM")) e->tune.finish_quorum = std::max(1, std::min(65, atoi(v)));
     if (const char* v = getenv("RT_PRIM_QUORUM")) e->tune.prim_quorum = std::max(1, std::min(65, atoi(v)));
     *out = e;
     return RT_OK;
@@ -1068,8 +1072,8 @@ int rt_engine_get_stats(rt_engine* e, rt_stats* out) {
             if (!p[0]) continue;
             const double w = (double)p[0], cyc = (double)p[1];
             const double iters = (double)p[11], lanes = (double)p[12];
-            fprintf(stderr, "%2d %6llu %9.0f %7.1f %5.1f %5.1f %5.1f %5.1f %7.1f %5.1f %6.1f %6.1f  box iters/wave %.0f lanes/iter %.1f\n", k, p[0], cyc / w, p[2] / w, 100.0 * p[3] / cyc,
-                    100.0 * p[4] / cyc, 100.0 * p[5] / cyc, 100.0 * p[6] / cyc, p[7] / w, p[7] ? (double)p[8] / p[7] : 0.0, p[9] / w, p[10] / w, iters / w, iters ? lanes / iters : 0.0);
+            fprintf(stderr, "%2d %6llu %9.0f %7.1f %5.1f %5.1f %5.1f %5.1f %7.1f %5.1f %6.1f %6.1f  box iters/wave %.0f lanes/iter %.1f  tri finishes/wave %.1f lanes %.1f\n", k, p[0], cyc / w, p[2] / w, 100.0 * p[3] / cyc,
+                    100.0 * p[4] / cyc, 100.0 * p[5] / cyc, 100.0 * p[6] / cyc, p[7] / w, p[7] ? (double)p[8] / p[7] : 0.0, p[9] / w, p[10] / w, iters / w, iters ? lanes / iters : 0.0, p[13] / w, p[13] ? (double)p[14] / p[13] : 0.0);
         }
     }
 #endif
