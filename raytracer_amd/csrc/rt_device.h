@@ -256,8 +256,7 @@ __device__ __forceinline__ int image_index(const rt::ImageRec im, float u, float
 __device__ __forceinline__ bool tri_reach(const float4* tris, int ti, const Ray& r, float& tt) {
     const float EPSILON = 0.0000001f;
     const float4* T = tris + (size_t)ti * rt::RT_TRI_F4;
-    const V3 v0 = xyz(T[0]), v1 = xyz(T[1]), v2 = xyz(T[2]);
-    const V3 edge1 = v1 - v0, edge2 = v2 - v0;
+    const V3 v0 = xyz(T[0]), edge1 = xyz(T[1]), edge2 = xyz(T[2]);
     const V3 h = cross(r.d, edge2);
     const float a = dot(edge1, h);
     if (a > -EPSILON && a < EPSILON) return false;
@@ -273,7 +272,8 @@ __device__ __forceinline__ bool tri_reach(const float4* tris, int ti, const Ray&
 }
 __device__ __forceinline__ bool tri_surface(const Scene& sc, const float4* tris, int ti, int alpha_off, uint32_t alpha_wh, const Ray& r, float tt, float& t, float& uo, float& vo, bool& wrote) {
     const float4* T = tris + (size_t)ti * rt::RT_TRI_F4;
-    const V3 p1 = xyz(T[0]), p2 = xyz(T[1]), p3 = xyz(T[2]);
+    const float4 ta = T[0], t5 = T[5];
+    const V3 p1 = xyz(ta), p2 = mk(ta.w, T[1].w, T[2].w), p3 = mk(t5.y, t5.z, t5.w);
     wrote = false;
     const V3 hp = r.o + r.d * tt;
     const float denominator = p1.y * (p2.z - p3.z) - p2.y * (p1.z - p3.z) + p3.y * (p1.z - p2.z);

@@ -755,7 +755,19 @@ int rt_engine_set_scene(rt_engine* e, const rt_scene* s) {
         }
     if (int rc = upload(&ent, inter.data(), inter.size() * 16)) return rc;
     e->scene_allocs.push_back(ent);
-    if (int rc = upload(&tris, f->tris.data(), f->tris.size() * 16)) return rc;
+    // device triangles carry the two edges Triangle::Intersect starts from (Object.cpp:503-504: the same float
+    // subtractions, done once here); the corners v1 and v2, needed only once the ray is known to reach the triangle,
+    // move to the spare lanes of the records
+    std::vector<rt::F4> dtris(f->tris);
+    for (size_t k = 0; k + rt::RT_TRI_F4 <= dtris.size(); k += rt::RT_TRI_F4) {
+        rt::F4* T = &dtris[k];
+        const rt::F4 v0 = T[0], v1 = T[1], v2 = T[2];
+        T[0] = rt::F4{v0.x, v0.y, v0.z, v1.x};
+        T[1] = rt::F4{v1.x - v0.x, v1.y - v0.y, v1.z - v0.z, v1.y};
+        T[2] = rt::F4{v2.x - v0.x, v2.y - v0.y, v2.z - v0.z, v1.z};
+        T[5] = rt::F4{T[5].x, v2.x, v2.y, v2.z};
+    }
+    if (int rc = upload(&tris, dtris.data(), dtris.size() * 16)) return rc;
     e->scene_allocs.push_back(tris);
     // one bit per texel of every image: "alpha byte > 0.01f" (DataUtility.cpp:123-127).  The padding row of the texel
     // pool (all zero) is covered too, because uv == 1 indexes one row past the image.
