@@ -835,11 +835,11 @@ __device__ __forceinline__ void walk_wave_to_end(const Scene& sc, const Store& s
 }
 __device__ __forceinline__ bool walker_is_idle(const Walker& w) { return sk_kind(w.sk) == rt::ENT_IDLE; }
 
-struct Hit { V3 point, normal; float u, v; int object; };
+struct Hit { V3 point, normal; float u, v; int object; bool sphere; };   // sphere: u, v are computed when a texture asks (sphere_uv)
 
 // The remaining HitInfo fields of the winning primitive (Object.cpp:21-25, 119-130, 145-147, 534-547 and the wrappers' way out)
 __device__ inline void finalize_hit(const Scene& sc, const Ray& ray, const Closest& c, Hit& h) {
-    h.u = 0; h.v = 0;
+    h.u = 0; h.v = 0; h.sphere = false;
     if (c.best <= -2) {
         const float4 pl = sc.planes[-(c.best + 2)];
         h.point = ray.o + ray.d * c.dist;
@@ -854,8 +854,7 @@ __device__ inline void finalize_hit(const Scene& sc, const Ray& ray, const Close
         h.point = ray.o + ray.d * c.dist;
         h.normal = normalize(h.point - xyz(ea));
         h.object = sk_payload(sk);
-        h.u = pm_atan2f(h.normal.x, h.normal.z) / (2 * 3.14159265358979323846264338327950288f) + 0.5f;
-        h.v = h.normal.y * 0.5f + 0.5f;
+        h.sphere = true;
     } else if (kind == rt::ENT_CUBE) {
         float t; V3 n;
         const V3 mn = xyz(ea), mx = mk(ea.w, eb.x, eb.y);
@@ -897,27 +896,57 @@ __device__ inline void finalize_hit(const Scene& sc, const Ray& ray, const Close
 }
 
 // ---------------------------------------------------------------------------------------------------- shading
+// byte / 255.0f (World.cpp:192, DataUtility.cpp:120): exactly the division, by two residual corrections of byte * RN(1/255)
+__device__ __forceinline__ V3 texel_color(const uint8_t* p) {
+    const float y = 1.0f / 255.0f;
+    return mk(div_by((float)p[0], 255.0f, y), div_by((float)p[1], 255.0f, y), div_by((float)p[2], 255.0f, y));
+}
 // World::GetSkyboxPixel (World.cpp:173-193): equirectangular nearest lookup without clamping
 __device__ inline V3 skybox_pixel(const Scene& sc, V3 d) {
     const float u = pm_atan2f(d.x, d.z) / (2 * 3.14159265358979323846264338327950288f) + 0.5f;
     const float v = d.y * 0.5f + 0.5f;
     const int ix = (int)(u * (float)sc.sky_w), iy = (int)(v * (float)sc.sky_h);
     const int index = 3 * (int)((uint32_t)iy * sc.sky_w + (uint32_t)ix);
-    const uint8_t* p = sc.texels + sc.sky_off + (uint32_t)index;
-    return divs(mk((float)p[0], (float)p[1], (float)p[2]), 255.0f);
+    return texel_color(sc.texels + sc.sky_off + (uint32_t)index);
+}
+// The sign of pm_sinf(x) without its polynomial: 1 negative, 0 positive, -1 when this shortcut cannot tell (the value is
+// or may round to zero, or x is not finite).  With r the reduced argument, |r| <= pi/4 plus rounding, and q the quadrant,
+// pm_sinf returns +-(r + r*(z*p)) with |z*p| < 0.2 for even q — the sign of r — and +-(1 - (z/2 - z*p)) >= 0.6 for odd q.
+__device__ __forceinline__ int pm_sinf_sign(float x) {
+    if (!(fabsf(x) <= FLT_MAX)) return -1;
+    const double TWO_OVER_PI = 6.36619772367581382433e-01;
+    const double P1 = 1.57079631090164184570e+00, P2 = 1.58932547122958567343e-08, P3 = 6.12323399573676603587e-17;
+    const double xd = (double)x;
+    const double k = rint(xd * TWO_OVER_PI);
+    const double r = ((xd - k * P1) - k * P2) - k * P3;
+    const int q = (int)(k - 4.0 * floor(k * 0.25));
+    if (!(q & 1) && !(fabs(r) > 1.0e-12)) return -1;    // sin(r) of a tiny r: its float may be 0 or underflow the product
+    const int neg = (q & 1) ? 0 : (r < 0.0 ? 1 : 0);
+    return neg ^ ((q >> 1) & 1);
+}
+// Sphere::Intersect's texture coordinates (Object.cpp:24-25), for the textures that read them
+__device__ __forceinline__ void sphere_uv(Hit& h) {
+    h.u = pm_atan2f(h.normal.x, h.normal.z) / (2 * 3.14159265358979323846264338327950288f) + 0.5f;
+    h.v = h.normal.y * 0.5f + 0.5f;
 }
 // Texture::GetColorValue of the three texture classes (DataUtility.h:91, DataUtility.cpp:84-96, 113-121)
-__device__ inline V3 texture_color(const Scene& sc, const float4* ob, const Hit& h) {
+__device__ inline V3 texture_color(const Scene& sc, const float4* ob, Hit& h) {
     const int kind = __float_as_int(ob[0].y);
     if (kind == 0) return xyz(ob[1]);
     if (kind == 1) {
+        // the checker only asks whether the product of three sines is negative: with every factor well away from zero
+        // that is the parity of their signs; otherwise the product itself is formed
         const float scale = 5.0f;
-        const float sines = pm_sinf(scale * h.point.x) * pm_sinf(scale * h.point.y) * pm_sinf(scale * h.point.z);
-        return (sines < 0.0f) ? xyz(ob[1]) : xyz(ob[2]);
+        const float ax = scale * h.point.x, ay = scale * h.point.y, az = scale * h.point.z;
+        const int sx = pm_sinf_sign(ax), sy = pm_sinf_sign(ay), sz = pm_sinf_sign(az);
+        bool negative;
+        if ((sx | sy | sz) >= 0) negative = ((sx ^ sy ^ sz) & 1) != 0;
+        else negative = pm_sinf(ax) * pm_sinf(ay) * pm_sinf(az) < 0.0f;
+        return negative ? xyz(ob[1]) : xyz(ob[2]);
     }
+    if (h.sphere) sphere_uv(h);
     const rt::ImageRec im = sc.images[__float_as_int(ob[0].z)];
-    const uint8_t* p = sc.texels + im.offset + (uint32_t)image_index(im, h.u, h.v);
-    return divs(mk((float)p[0], (float)p[1], (float)p[2]), 255.0f);
+    return texel_color(sc.texels + im.offset + (uint32_t)image_index(im, h.u, h.v));
 }
 
 }  // namespace rtd

@@ -438,6 +438,7 @@ __global__ __launch_bounds__(256) void trace_kernel(Scene sc, int n, const float
     if (!c.hit) { hit_id[i] = -1; for (int k = 1; k < 9; k++) q[k] = 0; return; }
     Hit h;
     finalize_hit(sc, r, c, h);
+    if (h.sphere) sphere_uv(h);   // the query reports HitInfo.uv whether or not a texture would read it
     hit_id[i] = h.object;
     q[1] = h.point.x; q[2] = h.point.y; q[3] = h.point.z; q[4] = h.normal.x; q[5] = h.normal.y; q[6] = h.normal.z; q[7] = h.u; q[8] = h.v;
 }

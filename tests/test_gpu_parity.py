@@ -75,6 +75,8 @@ def test_reciprocal_division_is_ieee_division(rt, gpu_default):
     a[:4096] = 0.0
     a[4096:8192] = -0.0
     a[8192:16384] = (b[8192:16384].astype(np.float64) * rng.integers(1, 1 << 24, 8192)).astype(np.float32)   # exact quotients
+    a[16384:16640] = np.arange(256)            # texel bytes over 255 (World.cpp:192, DataUtility.cpp:120)
+    b[16384:16640] = 255.0
     bad, first = e.check_division(a, b, seed=5, threads=1 << 22, rounds=256)
     assert bad == 0, f"{bad} quotients differ, first (a, b, got, want) = {first}"
 
