@@ -133,6 +133,22 @@ def pmc_traffic(path, kernel):
     return total if seen else None
 
 
+def pmc_active_lanes(path, kernel):
+    """Active-lane fraction SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU) per template variant of a kernel, from the
+    same summary."""
+    try:
+        lines = open(path).read().splitlines()
+    except OSError:
+        return None
+    out, name = {}, None
+    for ln in lines:
+        if not ln.startswith(" "):
+            name = ln.split("  dispatches")[0] if ln.startswith(kernel) else None
+        elif name and ln.split()[:2] == ["active-lane", "fraction"]:
+            out[name] = float(ln.split()[2])
+    return out or None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -234,11 +250,13 @@ def main():
         ach_gbs = stream_bytes / kern_s / 1e9 if kern_s > 0 else None
         # measured HBM traffic of the same kernel: PMC passes cannot run inside this process, so the figure comes from the
         # committed summary of tools/profile.sh runs of this command (C2, one GPU) and is null for anything else
-        traffic = None
+        traffic, lanes = None, None
         if args.workload == "c2" and world == 1 and kern_launches:
             per_frame = pmc_traffic(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_c2_pmc_summary.txt"),
                                     "intersect_kernel")
             traffic = per_frame / kern_launches if per_frame else None
+            lanes = pmc_active_lanes(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_c2_pmc_summary.txt"),
+                                     "intersect_kernel")
         out = {
             "metric": "Mrays/s", "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -254,7 +272,7 @@ def main():
                          "frac_of_unfused_peak": (ach_tflops / (PEAK_FP32_TFLOPS / 4)) if ach_tflops else None,
                          "kernel": "intersect_kernel", "launches": kern_launches,
                          "avg_launch_ms": (float(kt[0]) / kern_launches) if kern_launches else None,
-                         "flop_per_ray": flop_per_ray, "rays_per_launch": rays_rank0 / kern_launches if kern_launches else None},
+                         "active_lane_fraction": lanes, "flop_per_ray": flop_per_ray, "rays_per_launch": rays_rank0 / kern_launches if kern_launches else None},
             # the same kernel against HBM: ray records in, hit records out (the scene itself is read from LDS)
             "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                              "frac": (ach_gbs / PEAK_HBM_GBS) if ach_gbs else None, "traffic": traffic,
