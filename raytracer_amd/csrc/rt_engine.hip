@@ -36,6 +36,11 @@ using namespace rtd;
 namespace {
 
 constexpr int IBLOCK = 512;         // intersect: 8 waves per block; two blocks per CU, each with its own copy of the scene in LDS
+// Reservation counters of the intersect passes: the queue of a pass is cut into NCUR ranges with a counter each (a single
+// counter would take every reservation of the grid, and additions to one address are served one after another); the
+// counters of a pass lie CUR_STRIDE words apart so that they fall into different memory channels.
+constexpr int NCUR = 32, CUR_STRIDE = 1024;
+constexpr int COUNT_WORDS = CUR_STRIDE * (1 + NCUR);   // per batch: ray counts per pass, then NCUR rows of counters
 constexpr int STILE = 1024;         // shade: queue positions a block handles per round (survivors staged in 32 KiB of LDS)
 // intersect scheduling knobs (defaults in rt_engine_create; RT_REFILL_AT / RT_QUORUM / RT_CHUNK override them for tuning)
 struct Tune {
@@ -45,6 +50,7 @@ struct Tune {
     int chunk;       // queue positions a wave reserves per atomic (shrunk when a pass holds few rays)
     int prim_quorum; // lanes with an untested leaf needed to repeat the primitive-test phase
     int min_chunk;      // smallest reservation (64 to 128 is best: thinner spreading leaves lanes idle, thicker starves waves)
+    int guide;          // a reservation is 1/guide of an even share of the rays still in the queue
     int finish_quorum;  // lanes whose triangle waits for the second part of its test needed to run that part (1 measured best:
                         // a waiting lane tests no further leaf, and that costs more than running the part for few lanes)
 };
@@ -96,7 +102,7 @@ struct Queues {
     float4* hit;                     // hit records by queue position: (distance, best entry, u, v)
     uint32_t* hit_ctr;               // scenes with fog: the path's random-number counter after the traversal
     uint32_t* counts;                // counts[k] = rays entering pass k
-    uint32_t* cursors;               // cursors[k] = queue positions of pass k handed out to intersect waves so far
+    uint32_t* cursors;               // cursors[r * CUR_STRIDE + k] = positions of range r of pass k handed out to intersect waves so far
     float4* stack;                   // [depth][slot] = (texture colour rgb, factor)
     float4* radiance;                // [slot] = sample radiance
     int capacity;                    // slots
@@ -196,7 +202,9 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
     const Store st = stage_scene<STAGED>(sc, smem);
     const int qin = (pass + 1) & 1;
     const uint32_t n_in = FIRST ? (uint32_t)bt.n_pixels * (uint32_t)(g.S * g.S) : q.counts[pass];
-    uint32_t* cursor = &q.cursors[pass];
+    // a wave starts on the range of its block and moves on to the next when a range is used up
+    const uint32_t per_range = ((n_in + NCUR - 1) / NCUR + 63u) & ~63u;
+    uint32_t range = blockIdx.x % NCUR;
     const int lane = (int)(threadIdx.x & 63u);
     const unsigned long long below = (1ull << lane) - 1ull;
     Walker w;
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
     uint32_t mine = 0, mine_end = 0;
     // few rays in the pass: smaller reservations, so that every wave of the grid gets some
     const uint32_t waves = gridDim.x * (IBLOCK / 64);
-    uint32_t chunk = (n_in / (waves * 2u)) & ~7u;
+    uint32_t chunk = (n_in / (waves * (uint32_t)tune.guide)) & ~7u;
     chunk = chunk < (uint32_t)tune.min_chunk ? (uint32_t)tune.min_chunk : (chunk > (uint32_t)tune.chunk ? (uint32_t)tune.chunk : chunk);
     bool drained = false;   // wave-uniform: every queue position has been handed out
     Prof prof;
@@ -216,15 +224,37 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
         const unsigned long long idle = __ballot(walker_is_idle(w));
         if (!drained && __popcll(idle) >= (FIRST ? tune.refill_at : tune.refill_at_bounce)) {
             if (mine == mine_end) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(cursor, chunk);
-                base = (uint32_t)__shfl((int)base, 0);
-                mine = base < n_in ? base : n_in;
-                mine_end = base + chunk < n_in ? base + chunk : n_in;
-                // guided: the next reservation shrinks with what is left, so that the waves run out of work together
-                const uint32_t left = n_in - mine_end;
-                chunk = (left / (waves * 2u)) & ~7u;
-                chunk = chunk < (uint32_t)tune.min_chunk ? (uint32_t)tune.min_chunk : (chunk > (uint32_t)tune.chunk ? (uint32_t)tune.chunk : chunk);
+                for (;;) {
+                    const uint32_t r_begin = range * per_range < n_in ? range * per_range : n_in;
+                    const uint32_t r_end = r_begin + per_range < n_in ? r_begin + per_range : n_in;
+                    uint32_t off = 0xFFFFFFFFu;
+                    if (r_begin < r_end) {
+                        if (lane == 0) off = atomicAdd(q.cursors + range * CUR_STRIDE + pass, chunk);
+                        off = (uint32_t)__shfl((int)off, 0);
+                    }
+                    if (off < r_end - r_begin) {
+                        mine = r_begin + off;
+                        mine_end = mine + chunk < r_end ? mine + chunk : r_end;
+                        // guided: the next reservation shrinks with what is left, so that the waves run out of work together
+                        const uint32_t left = (r_end - mine_end) * NCUR;
+                        chunk = (left / (waves * (uint32_t)tune.guide)) & ~7u;
+                        chunk = chunk < (uint32_t)tune.min_chunk ? (uint32_t)tune.min_chunk : (chunk > (uint32_t)tune.chunk ? (uint32_t)tune.chunk : chunk);
+                        break;
+                    }
+                    // this range is used up: lane r looks at range r's counter, the wave moves to the range with the most left
+                    uint32_t left = 0;
+                    if (lane < NCUR) {
+                        const uint32_t b = (uint32_t)lane * per_range < n_in ? (uint32_t)lane * per_range : n_in;
+                        const uint32_t size = (b + per_range < n_in ? b + per_range : n_in) - b;
+                        const uint32_t seen = __hip_atomic_load(q.cursors + lane * CUR_STRIDE + pass, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        left = seen < size ? size - seen : 0u;
+                    }
+                    uint32_t best = left << 6 | (uint32_t)lane;          // left < 2^26: a queue holds fewer than 2^31 positions, a range 1/32 of them
+                    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)best, d); best = o > best ? o : best; }
+                    if ((best >> 6) == 0u) break;                         // nothing left anywhere
+                    range = best & 63u;
+                    chunk = (uint32_t)tune.min_chunk;
+                }
             }
             if (mine == mine_end) drained = true;
             else {
@@ -530,7 +560,7 @@ struct rt_engine {
     Debug dbg{nullptr, nullptr, nullptr, nullptr, nullptr};
     bool debug_valid = false;
     int n_cus = 0;
-    Tune tune{32, 16, 8, 512, 16, 64, 1};
+    Tune tune{32, 16, 8, 256, 16, 64, 16, 1};
     int win[4] = {0, 0, 0, 0};          // x0, y0, width, height of the render window
     // statistics of the last render
     std::vector<uint32_t> h_counts;     // per batch: counts (B + 2), cursors (B + 2)
@@ -608,11 +638,11 @@ void launch_intersect(rt_engine* e, hipStream_t st, const Cfg& g, const Batch& b
 }
 
 // the passes of one batch: pass 0 generates its rays, passes 1..B read the queue the previous pass filled.  counts points
-// at 2 * (B + 2) zeroed words: ray counts, then intersect cursors.
+// at COUNT_WORDS zeroed words: ray counts, then the intersect passes' reservation counters.
 int run_passes(rt_engine* e, const Batch& bt, hipStream_t st, uint32_t* counts, bool first_from_queue, int bounces) {
     Queues q = e->q;
     q.counts = counts;
-    q.cursors = counts + e->n_counts;
+    q.cursors = counts + CUR_STRIDE;
     Cfg g = make_cfg(e->cfg);
     g.B = bounces;
     const int shade_blocks = e->n_cus * 8;
@@ -688,6 +718,7 @@ int rt_engine_create(const rt_config* cfg, rt_engine** out) {
     if (const char* v = getenv("RT_QUORUM")) e->tune.quorum = std::max(1, std::min(65, atoi(v)));
     if (const char* v = getenv("RT_CHUNK")) e->tune.chunk = std::max(64, atoi(v) & ~63);
     if (const char* v = getenv("RT_MIN_CHUNK")) e->tune.min_chunk = std::max(8, atoi(v) & ~7);
+    if (const char* v = getenv("RT_GUIDE")) e->tune.guide = std::max(1, std::min(64, atoi(v)));
     if (const char* v = getenv("RT_FINISH_QUORUM")) e->tune.finish_quorum = std::max(1, std::min(65, atoi(v)));
     if (const char* v = getenv("RT_PRIM_QUORUM")) e->tune.prim_quorum = std::max(1, std::min(65, atoi(v)));
     *out = e;
@@ -870,7 +901,7 @@ int rt_engine_render(rt_engine* e, uint32_t seed, int rank, int n_ranks, uint8_t
     const long long my_pixels = (long long)tiles_per_rank(e, n_ranks) * per_tile;
     const int batch_pixels = e->q.capacity / spp;
     const int n_batches = (int)((my_pixels + batch_pixels - 1) / batch_pixels);
-    const int per_batch = 2 * e->n_counts;
+    const int per_batch = COUNT_WORDS;
     if (n_batches * per_batch > e->counts_capacity) {
         (void)hipFree(e->d_counts_all);
         e->counts_capacity = n_batches * per_batch;
@@ -1034,7 +1065,7 @@ int rt_engine_ray_color(rt_engine* e, int n, const float* o3, const float* d3, i
     int rc = RT_OK;
     if ((rc = upload(&d_o, o3, (size_t)n * 12)) == RT_OK && (rc = upload(&d_d, d3, (size_t)n * 12)) == RT_OK &&
         (rc = upload(&d_keys, keys, (size_t)n * 4)) == RT_OK) {
-        const size_t words = 2 * (size_t)e->n_counts;
+        const size_t words = COUNT_WORDS;
         if (hipMalloc((void**)&d_counts, sizeof(uint32_t) * words) != hipSuccess) rc = fail(RT_E_NOMEM, "device allocation failed");
         else {
             (void)hipMemsetAsync(d_counts, 0, sizeof(uint32_t) * words, e->stream);
@@ -1068,7 +1099,7 @@ int rt_engine_get_stats(rt_engine* e, rt_stats* out) {
     HIP_TRY(hipSetDevice(e->cfg.device));
     HIP_TRY(hipStreamSynchronize(e->stream));
     memset(out, 0, sizeof *out);
-    const int nb = e->last_batches, nc = e->n_counts, per_batch = 2 * nc;
+    const int nb = e->last_batches, nc = e->n_counts, per_batch = COUNT_WORDS;
     if (nb <= 0) return RT_OK;
     e->h_counts.resize((size_t)nb * per_batch);
     HIP_TRY(hipMemcpy(e->h_counts.data(), e->d_counts_all, sizeof(uint32_t) * (size_t)nb * per_batch, hipMemcpyDeviceToHost));
