@@ -40,6 +40,7 @@ constexpr int IBLOCK = 512;         // intersect: 8 waves per block; two blocks 
 // counter would take every reservation of the grid, and additions to one address are served one after another); the
 // counters of a pass lie CUR_STRIDE words apart so that they fall into different memory channels.
 constexpr int NCUR = 32, CUR_STRIDE = 1024;
+constexpr int STRIPE = 512;
 constexpr int COUNT_WORDS = CUR_STRIDE * (1 + NCUR);   // per batch: ray counts per pass, then NCUR rows of counters
 constexpr int STILE = 1024;         // shade: queue positions a block handles per round (survivors staged in 32 KiB of LDS)
 // intersect scheduling knobs (defaults in rt_engine_create; RT_REFILL_AT / RT_QUORUM / RT_CHUNK override them for tuning)
@@ -195,6 +196,10 @@ __device__ __forceinline__ Store stage_scene(const Scene& sc, float4* smem) {
     return st;
 }
 
+// offsets range r spans: STRIPE for each of its stripes (the queue's last stripe may hold fewer positions: those past the
+// end are skipped when they come up)
+__device__ __forceinline__ uint32_t range_size(uint32_t n_stripes, uint32_t r) { return r < n_stripes ? ((n_stripes - r + NCUR - 1) / NCUR) * STRIPE : 0u; }
+
 // ---- intersect (World.cpp:105-119) ----------------------------------------------------------------------------------
 template <bool FIRST, bool STAGED, bool FOG>
 __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cfg g, Batch bt, Queues q, int pass, Debug dbg, Tune tune) {
@@ -202,8 +207,11 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
     const Store st = stage_scene<STAGED>(sc, smem);
     const int qin = (pass + 1) & 1;
     const uint32_t n_in = FIRST ? (uint32_t)bt.n_pixels * (uint32_t)(g.S * g.S) : q.counts[pass];
-    // a wave starts on the range of its block and moves on to the next when a range is used up
-    const uint32_t per_range = ((n_in + NCUR - 1) / NCUR + 63u) & ~63u;
+    // Range r of the queue is every NCUR-th stripe of STRIPE positions, starting with stripe r: all ranges move through
+    // the queue side by side, so the grid still works on one neighbourhood of the image at a time.  A wave starts on the
+    // range of its block and moves on when a range is used up.  Offset o of range r is queue position
+    // ((o / STRIPE) * NCUR + r) * STRIPE + o % STRIPE.
+    const uint32_t n_stripes = (n_in + STRIPE - 1) / STRIPE;
     uint32_t range = blockIdx.x % NCUR;
     const int lane = (int)(threadIdx.x & 63u);
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -211,7 +219,7 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
     walker_idle(sc, w);
     uint32_t my_idx = 0;
     // the wave owns queue positions [mine, mine_end); it reserves CHUNK more with one atomic when they run out
-    uint32_t mine = 0, mine_end = 0;
+    uint32_t mine = 0, mine_end = 0, mine_range = 0;   // as offsets of range mine_range
     // few rays in the pass: smaller reservations, so that every wave of the grid gets some
     const uint32_t waves = gridDim.x * (IBLOCK / 64);
     uint32_t chunk = (n_in / (waves * (uint32_t)tune.guide)) & ~7u;
@@ -225,18 +233,18 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
         if (!drained && __popcll(idle) >= (FIRST ? tune.refill_at : tune.refill_at_bounce)) {
             if (mine == mine_end) {
                 for (;;) {
-                    const uint32_t r_begin = range * per_range < n_in ? range * per_range : n_in;
-                    const uint32_t r_end = r_begin + per_range < n_in ? r_begin + per_range : n_in;
+                    const uint32_t size = range_size(n_stripes, range);
                     uint32_t off = 0xFFFFFFFFu;
-                    if (r_begin < r_end) {
+                    if (size) {
                         if (lane == 0) off = atomicAdd(q.cursors + range * CUR_STRIDE + pass, chunk);
                         off = (uint32_t)__shfl((int)off, 0);
                     }
-                    if (off < r_end - r_begin) {
-                        mine = r_begin + off;
-                        mine_end = mine + chunk < r_end ? mine + chunk : r_end;
+                    if (off < size) {
+                        mine = off;
+                        mine_end = off + chunk < size ? off + chunk : size;
+                        mine_range = range;
                         // guided: the next reservation shrinks with what is left, so that the waves run out of work together
-                        const uint32_t left = (r_end - mine_end) * NCUR;
+                        const uint32_t left = (size - mine_end) * NCUR;
                         chunk = (left / (waves * (uint32_t)tune.guide)) & ~7u;
                         chunk = chunk < (uint32_t)tune.min_chunk ? (uint32_t)tune.min_chunk : (chunk > (uint32_t)tune.chunk ? (uint32_t)tune.chunk : chunk);
                         break;
@@ -244,10 +252,9 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
                     // this range is used up: lane r looks at range r's counter, the wave moves to the range with the most left
                     uint32_t left = 0;
                     if (lane < NCUR) {
-                        const uint32_t b = (uint32_t)lane * per_range < n_in ? (uint32_t)lane * per_range : n_in;
-                        const uint32_t size = (b + per_range < n_in ? b + per_range : n_in) - b;
+                        const uint32_t sz = range_size(n_stripes, (uint32_t)lane);
                         const uint32_t seen = __hip_atomic_load(q.cursors + lane * CUR_STRIDE + pass, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        left = seen < size ? size - seen : 0u;
+                        left = seen < sz ? sz - seen : 0u;
                     }
                     uint32_t best = left << 6 | (uint32_t)lane;          // left < 2^26: a queue holds fewer than 2^31 positions, a range 1/32 of them
                     for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)best, d); best = o > best ? o : best; }
@@ -258,8 +265,9 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
             }
             if (mine == mine_end) drained = true;
             else {
-                const uint32_t idx = mine + (uint32_t)__popcll(idle & below);
-                if (walker_is_idle(w) && idx < mine_end) {
+                const uint32_t o = mine + (uint32_t)__popcll(idle & below);
+                const uint32_t idx = ((o / STRIPE) * NCUR + mine_range) * STRIPE + o % STRIPE;
+                if (walker_is_idle(w) && o < mine_end && idx < n_in) {
                     Ray ray; Rng rng; uint32_t slot, depth;
                     if (fetch_ray<FIRST>(cam, g, bt, q, qin, dbg, idx, ray, rng, slot, depth, FOG)) {
                         my_idx = idx;
