@@ -146,6 +146,16 @@ __device__ __forceinline__ Ray camera_ray(const Cam& cam, const Cfg& g, int px, 
     return r;
 }
 
+// The random stream of the path in `slot`: keyed by (frame seed, pixel, sample) (or given by the caller of a ray query)
+__device__ __forceinline__ uint32_t slot_key(const Cfg& g, const Batch& bt, const Debug& dbg, uint32_t slot) {
+    if (dbg.keys) return dbg.keys[slot];
+    const int spp = g.S * g.S;
+    const int lp = (int)fdiv(slot, g.div_spp), s = (int)(slot - (uint32_t)lp * (uint32_t)spp);
+    int px = 0, py = 0;
+    pixel_of(bt, bt.first_pixel + lp, px, py);
+    return sample_key(bt.seed, (uint32_t)(py * g.W + px), (uint32_t)s);
+}
+
 // The ray at queue position `idx` of a pass.  FIRST: generated from the camera (slot = idx); otherwise read from queue
 // `qin`.  Returns false for a position that holds no ray (a pixel outside the frame in a partial tile).
 template <bool FIRST>
@@ -168,14 +178,9 @@ __device__ __forceinline__ bool fetch_ray(const Cam& cam, const Cfg& g, const Ba
     slot = __float_as_uint(b.z);
     const uint32_t cd = __float_as_uint(b.w);
     rng.ctr = cd & 0xFFFFFFu; depth = cd >> 24;
-    if (!need_rng) rng.key = 0;                   // the closest-hit search of a scene without fog draws nothing
-    else if (dbg.keys) rng.key = dbg.keys[slot];
-    else {
-        const int lp = (int)fdiv(slot, g.div_spp), s = (int)(slot - (uint32_t)lp * (uint32_t)spp);
-        int px = 0, py = 0;
-        pixel_of(bt, bt.first_pixel + lp, px, py);
-        rng.key = sample_key(bt.seed, (uint32_t)(py * g.W + px), (uint32_t)s);
-    }
+    // the closest-hit search of a scene without fog draws nothing, and many rays end without a draw: those callers ask
+    // for the key (slot_key) only when a draw comes up
+    rng.key = need_rng ? slot_key(g, bt, dbg, slot) : 0u;
     return true;
 }
 
@@ -306,7 +311,7 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
 // path goes on: `next` is the bounce ray, the (factor, texture colour) of this bounce is on the path's colour stack.
 // Otherwise the path ends here: the stack is unwound and the sample's radiance stored.
 template <bool FIRST>
-__device__ __forceinline__ bool shade_ray(const Scene& sc, const Cfg& g, const Queues& q, const Debug& dbg, const Ray& ray, Rng& rng,
+__device__ __forceinline__ bool shade_ray(const Scene& sc, const Cfg& g, const Batch& bt, const Queues& q, const Debug& dbg, const Ray& ray, Rng& rng,
                                           uint32_t slot, uint32_t depth, const Closest& c, Ray& next) {
     bool alive = false;
     Hit h;
@@ -325,6 +330,7 @@ __device__ __forceinline__ bool shade_ray(const Scene& sc, const Cfg& g, const Q
         else if (mtype != RT_MAT_NONE && remaining != 0) {
             float factor = 1.0f;
             next.o = h.point;
+            if (!FIRST && mtype != RT_MAT_METAL) rng.key = slot_key(g, bt, dbg, slot);   // the bounce draws: now the stream is needed
             if (mtype == RT_MAT_DIFFUSE) {
                 next.d = normalize(h.normal + unit_sphere_point(rng));
                 factor = 0.5f;                        // lightDarknerFactor (World.cpp:129)
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(256) void shade_kernel(Scene sc, Cam cam, Cfg g, Ba
         Rng rng;
         uint32_t slot = 0, depth = 0;
         ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1); rng.key = 0; rng.ctr = 0;
-        const bool live = i < n_in && fetch_ray<FIRST>(cam, g, bt, q, qin, dbg, i, ray, rng, slot, depth);
+        const bool live = i < n_in && fetch_ray<FIRST>(cam, g, bt, q, qin, dbg, i, ray, rng, slot, depth, FIRST);
         bool alive = false;        // continues into the next pass
         Ray next = ray;
         if (live) {
@@ -376,7 +382,7 @@ __global__ __launch_bounds__(256) void shade_kernel(Scene sc, Cam cam, Cfg g, Ba
             if (sc.has_fog) rng.ctr = q.hit_ctr[i];      // fog volumes drew random numbers during the traversal
             Closest c;
             c.dist = hr.x; c.best = __float_as_int(hr.y); c.u = hr.z; c.v = hr.w; c.hit = c.best != -1;
-            alive = shade_ray<FIRST>(sc, g, q, dbg, ray, rng, slot, depth, c, next);
+            alive = shade_ray<FIRST>(sc, g, bt, q, dbg, ray, rng, slot, depth, c, next);
         }
         // compact: survivors of this wave (ballot + prefix count) take consecutive places in the block's staging tile
         const unsigned long long mask = __ballot(alive);
