@@ -10,7 +10,7 @@ distances are bit-exact; 8-bit colour may differ where libm's sinf/atan2f and th
 import numpy as np
 import pytest
 
-from conftest import assert_bits, build_table_scene, synthetic_tables
+from conftest import assert_bits, build_table_scene, random_tables, synthetic_tables
 
 pytestmark = pytest.mark.gpu
 
@@ -486,36 +486,6 @@ def test_degenerate_scenes_and_sizes(rt, orc, assets, case):
     assert_bits(got["rng_draws"], ref["rng_draws"], case + ": RNG draws")
     assert_bits(got["radiance"], ref["radiance"], case + ": radiance")
     assert_bits(frame, ref["rgba"], case + ": frame")
-
-
-def random_tables(seed):
-    """a small scene drawn from a seeded generator: every primitive kind, texture kind, material, rotation axis and
-    wrapper, at sizes and places that make them overlap"""
-    r = np.random.default_rng(seed)
-    tex = [[0, *r.uniform(0.1, 1.0, 3), 0, 0, 0], [1, *r.uniform(0.1, 1.0, 3), *r.uniform(0.1, 1.0, 3)], [2, 0, 0, 0, 0, 0, 0]]
-    mat = [[1, 0, 0, 0, 0], [1, 1, 0, 0, 0], [1, 2, 0, 0, 0], [2, 0, 0, 0, 0], [2, 1, 0, 0, 0], [3, 0, 0, 0, 0], [4, -1, *r.uniform(1.0, 6.0, 3)],
-           [0, -1, 0, 0, 0]]
-    obj = []
-    for _ in range(int(r.integers(6, 40))):
-        k = int(r.choice([0, 0, 0, 1, 2, 4]))
-        c = r.uniform(-12, 12, 3) * [1, 0.4, 1] + [0, 3, 8]
-        m = int(r.integers(0, len(mat)))
-        if k == 0:
-            obj.append([0, *c, float(r.choice([1, 1, 1, -1])) * r.uniform(0.3, 3.0), 0, 0, 0, 0, m])
-        elif k == 1:
-            h = r.uniform(0.3, 2.5, 3)
-            obj.append([1, *(c - h), *(c + h), 0, 0, m])
-        elif k == 2:
-            obj.append([2, *c, r.uniform(0.3, 2.5), 0, 0, 0, 0, m])
-        else:
-            obj.append([4, *c, r.uniform(1.0, 5.0), r.uniform(0.02, 0.6), int(r.integers(-1, 3)), r.uniform(0, 360),
-                        float(r.choice([0.0, 0.0, r.uniform(-3, 3)])), 5])
-    for _ in range(int(r.integers(0, 3))):   # mesh instances: scale, rotation axis, degrees, offset, offset present, material (image texture)
-        mv = r.uniform(-6, 6, 3) * [1, 0.2, 1] + [0, 2, 6]
-        obj.append([3, r.uniform(2, 9), int(r.integers(-1, 3)), r.uniform(0, 360), *mv, int(r.integers(0, 2)), 0, int(r.choice([2, 2, 0, 3]))])
-    plane = [[float(r.uniform(-1, 1)), int(r.choice([0, 1, 3, 4]))] for _ in range(int(r.integers(0, 3)))]
-    cam = (r.uniform(-6, 6), r.uniform(1, 6), r.uniform(-14, -6)), (r.uniform(-0.3, 0.3), r.uniform(-0.2, 0.1), 1.0)
-    return np.array(tex, np.float32), np.array(mat, np.float32), np.array(obj, np.float32), plane, cam
 
 
 @pytest.mark.parametrize("seed", [101, 202, 303, 404, 505, 606, 707, 808])
