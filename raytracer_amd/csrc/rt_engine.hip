@@ -14,9 +14,9 @@
 //
 // A path owns a slot in the batch, slot = pixel * spp + sample: the 64 lanes of a wave start on the samples of one pixel,
 // as coherent as primary rays get (enumerating the paths sample-major instead costs the first intersect pass 20 %).
-// Its RNG stream is keyed by (frame seed, pixel, sample), so the result of a slot does not depend on scheduling.  The recursion of World::GetRayColor multiplies colours on the way back (innermost first);
-// to reproduce that rounding order every bounce stores its (factor, texture colour) in a per-slot stack which the
-// terminating pass unwinds.
+// Its RNG stream is keyed by (frame seed, pixel, sample), so the result of a slot does not depend on scheduling.  The
+// recursion of World::GetRayColor multiplies colours on the way back (innermost first); to reproduce that rounding order
+// every bounce stores its (factor, texture colour) in a per-slot stack which the terminating pass unwinds.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -40,7 +40,7 @@ constexpr int IBLOCK = 512;         // intersect: 8 waves per block; two blocks 
 // counter would take every reservation of the grid, and additions to one address are served one after another); the
 // counters of a pass lie CUR_STRIDE words apart so that they fall into different memory channels.
 constexpr int NCUR = 32, CUR_STRIDE = 1024;
-constexpr int STRIPE = 512;
+constexpr int STRIPE = 512;          // positions per stripe; range r of a queue is every NCUR-th stripe, starting with stripe r
 constexpr int COUNT_WORDS = CUR_STRIDE * (1 + NCUR);   // per batch: ray counts per pass, then NCUR rows of counters
 constexpr int STILE = 1024;         // shade: queue positions a block handles per round (survivors staged in 32 KiB of LDS)
 // intersect scheduling knobs (defaults in rt_engine_create; RT_REFILL_AT / RT_QUORUM / RT_CHUNK override them for tuning)
