@@ -678,6 +678,8 @@ int run_passes(rt_engine* e, const Batch& bt, hipStream_t st, uint32_t* counts, 
     return RT_OK;
 }
 
+int init_engine(rt_engine* e, const rt_config* cfg);
+
 }  // namespace
 
 extern "C" {
@@ -692,6 +694,16 @@ int rt_engine_create(const rt_config* cfg, rt_engine** out) {
     if (cfg->device < 0 || cfg->device >= n_dev) return fail(RT_E_DEVICE, "no such HIP device");
     HIP_TRY(hipSetDevice(cfg->device));
     rt_engine* e = new rt_engine();
+    const int rc = init_engine(e, cfg);
+    if (rc != RT_OK) { rt_engine_destroy(e); return rc; }    // whatever was allocated before the failure goes back
+    *out = e;
+    return RT_OK;
+}
+
+}  // extern "C"
+
+namespace {
+int init_engine(rt_engine* e, const rt_config* cfg) {
     e->cfg = *cfg;
     if (e->cfg.tile_w <= 0) e->cfg.tile_w = 64;
     if (e->cfg.tile_h <= 0) e->cfg.tile_h = 64;
@@ -735,9 +747,11 @@ int rt_engine_create(const rt_config* cfg, rt_engine** out) {
     if (const char* v = getenv("RT_GUIDE")) e->tune.guide = std::max(1, std::min(64, atoi(v)));
     if (const char* v = getenv("RT_FINISH_QUORUM")) e->tune.finish_quorum = std::max(1, std::min(65, atoi(v)));
     if (const char* v = getenv("RT_PRIM_QUORUM")) e->tune.prim_quorum = std::max(1, std::min(65, atoi(v)));
-    *out = e;
     return RT_OK;
 }
+}  // namespace
+
+extern "C" {
 
 void rt_engine_destroy(rt_engine* e) {
     if (!e) return;
@@ -749,7 +763,7 @@ void rt_engine_destroy(rt_engine* e) {
     (void)hipFree(e->q.stack); (void)hipFree(e->q.radiance); (void)hipFree(e->d_frame); (void)hipFree(e->d_counts_all);
     (void)hipFree(e->dbg.primary_id); (void)hipFree(e->dbg.primary_t); (void)hipFree(e->dbg.rng_draws);
     for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
-    (void)hipStreamDestroy(e->stream);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
 
