@@ -680,11 +680,13 @@ __device__ __forceinline__ void box_steps(const Store& st, Walker& w, int quorum
                  "s_and_b64 exec, %[saved], %[mall]\n\t"
                  RT_BOX_COUNT
                  "v_lshlrev_b32_e32 v2, 5, %[i]\n\t"
-                 "global_load_dwordx2 %[e01], v2, %[base]\n\t"
-                 "global_load_dwordx2 %[e23], v2, %[base] offset:8\n\t"
-                 "global_load_dwordx2 %[e45], v2, %[base] offset:16\n\t"
-                 "global_load_dword %[sk], v2, %[base] offset:24\n\t"
+                 "global_load_dwordx4 v[10:13], v2, %[base]\n\t"
+                 "global_load_dwordx4 v[14:17], v2, %[base] offset:16\n\t"
                  "s_waitcnt vmcnt(0)\n\t"
+                 "v_pk_mov_b32 %[e01], v[10:11], v[10:11] op_sel:[0,1]\n\t"
+                 "v_pk_mov_b32 %[e23], v[12:13], v[12:13] op_sel:[0,1]\n\t"
+                 "v_pk_mov_b32 %[e45], v[14:15], v[14:15] op_sel:[0,1]\n\t"
+                 "v_mov_b32_e32 %[sk], v16\n\t"
                  "s_mov_b64 exec, %[saved]\n\t"
                  "s_bcnt1_i32_b64 %[cntS], %[m]\n\t"
                  "s_cmp_ge_u32 %[cntS], %[quorum]\n\t"
