@@ -209,9 +209,12 @@ __device__ __forceinline__ uint32_t range_size(uint32_t n_stripes, uint32_t r) {
 template <bool FIRST, bool STAGED, bool FOG>
 __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cfg g, Batch bt, Queues q, int pass, Debug dbg, Tune tune) {
     extern __shared__ float4 smem[];
+    const uint32_t n_in = FIRST ? (uint32_t)bt.n_pixels * (uint32_t)(g.S * g.S) : q.counts[pass];
+    // a pass with few rays: blocks beyond one smallest reservation per wave leave before they copy the scene
+    const uint32_t blocks_used = min((uint32_t)gridDim.x, n_in / ((uint32_t)tune.min_chunk * (IBLOCK / 64)) + 1u);
+    if (n_in == 0u || blockIdx.x >= blocks_used) return;
     const Store st = stage_scene<STAGED>(sc, smem);
     const int qin = (pass + 1) & 1;
-    const uint32_t n_in = FIRST ? (uint32_t)bt.n_pixels * (uint32_t)(g.S * g.S) : q.counts[pass];
     // Range r of the queue is every NCUR-th stripe of STRIPE positions, starting with stripe r: all ranges move through
     // the queue side by side, so the grid still works on one neighbourhood of the image at a time.  A wave starts on the
     // range of its block and moves on when a range is used up.  Offset o of range r is queue position
@@ -226,7 +229,7 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
     // the wave owns queue positions [mine, mine_end); it reserves CHUNK more with one atomic when they run out
     uint32_t mine = 0, mine_end = 0, mine_range = 0;   // as offsets of range mine_range
     // few rays in the pass: smaller reservations, so that every wave of the grid gets some
-    const uint32_t waves = gridDim.x * (IBLOCK / 64);
+    const uint32_t waves = blocks_used * (IBLOCK / 64);
     uint32_t chunk = (n_in / (waves * (uint32_t)tune.guide)) & ~7u;
     chunk = chunk < (uint32_t)tune.min_chunk ? (uint32_t)tune.min_chunk : (chunk > (uint32_t)tune.chunk ? (uint32_t)tune.chunk : chunk);
     bool drained = false;   // wave-uniform: every queue position has been handed out
