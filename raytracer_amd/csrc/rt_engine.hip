@@ -885,7 +885,7 @@ int rt_engine_set_scene(rt_engine* e, const rt_scene* s) {
     sc.idle_entry = f->idle_entry;
     sc.has_fog = has_fog ? 1 : 0;
     e->sc = sc;
-    // stage the whole scene in LDS when two 1024-thread blocks per CU can each hold it (160 KiB per CU)
+    // stage the whole scene in LDS when two 512-thread blocks per CU can each hold it (160 KiB per CU)
     const size_t need = (inter.size() + f->tris.size() + f->inst.size() + f->planes.size()) * 16;
     e->staged_bytes = need <= 80 * 1024 ? need : 0;
     if (e->staged_bytes) {
