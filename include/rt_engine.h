@@ -132,8 +132,10 @@ int rt_engine_get_config(const rt_engine* e, rt_config* out);
  * rank r of n renders tiles r, r+n, r+2n, ...
  *   n_ranks == 1: d_rgba (device pointer, NULL = the engine's own frame buffer) receives the whole frame:
  *                 width*height*4 bytes, [A=255,B,G,R] per pixel, row-major, top row first (FrameManager.cpp:89-94).
- *   n_ranks  > 1: d_rgba receives rt_engine_tile_bytes() bytes: this rank's tiles packed one after another, each
- *                 tile_h x tile_w x 4; slots beyond the rank's tile count stay zero. */
+ *   n_ranks  > 1: d_rgba (required: the engine's own frame buffer may be smaller than a rank's padded tiles) receives
+ *                 rt_engine_tile_bytes() bytes: this rank's tiles packed one after another, each tile_h x tile_w x 4;
+ *                 slots beyond the rank's tile count stay zero.
+ * Rendering allocates nothing: queues and counters are sized when the engine is created. */
 int rt_engine_render(rt_engine* e, uint32_t frame_seed, int rank, int n_ranks, uint8_t* d_rgba, void* stream);
 int64_t rt_engine_tile_bytes(const rt_engine* e, int n_ranks);         /* per-rank packed size, equal on all ranks */
 /* Restrict following renders to the pixel rectangle [x0,x1) x [y0,y1) of the frame (tiles are then cut from the window;
@@ -142,7 +144,11 @@ int64_t rt_engine_tile_bytes(const rt_engine* e, int n_ranks);         /* per-ra
 int rt_engine_set_window(rt_engine* e, int x0, int y0, int x1, int y1);
 /* Scatter gathered tiles (n_ranks packed buffers back to back, as an all-gather / gather leaves them) into a frame. */
 int rt_engine_assemble(rt_engine* e, const uint8_t* d_gathered, int n_ranks, uint8_t* d_rgba, void* stream);
-int rt_engine_sync(rt_engine* e);                                      /* waits for the engine's stream */
+/* Waits for everything the engine has queued: its own stream and, when the latest rt_engine_render / rt_engine_assemble
+ * was given a stream of the caller's, that stream as well.  rt_engine_poll, rt_engine_read_frame, rt_engine_get_stats
+ * and rt_engine_set_scene follow the same rule.  A caller that spreads work over several streams of its own orders
+ * them itself. */
+int rt_engine_sync(rt_engine* e);
 /* 1 when everything queued on the engine's stream has finished, 0 while work is still running — what the front end's
  * FrameManager::NeedUpdatingTexture (FrameManager.cpp:40-48) learns from its per-thread flags.  Never blocks. */
 int rt_engine_poll(rt_engine* e);

@@ -10,6 +10,8 @@
 
 #include <zlib.h>
 
+#include <algorithm>
+
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -141,7 +143,12 @@ bool load_png(const std::string& path, int req_channels, bool flip, std::vector<
         if (p + 12 + (size_t)len > file.size()) { err = "truncated PNG " + path; return false; }
         const uint8_t* d = &file[p + 8];
         if (!memcmp(type, "IHDR", 4)) {
-            w = (int)be32(d); h = (int)be32(d + 4); depth = d[8]; ctype = d[9]; interlace = d[12];
+            if (len != 13) { err = "bad PNG header in " + path; return false; }
+            const uint32_t uw = be32(d), uh = be32(d + 4);
+            // bounds that keep every size computed below far from overflow and from absurd allocations: 2^15 texels per
+            // side is what the texture lookups can address with their 16-bit sizes anyway
+            if (uw == 0 || uh == 0 || uw > 32768u || uh > 32768u) { err = "PNG dimensions out of range (1..32768) in " + path; return false; }
+            w = (int)uw; h = (int)uh; depth = d[8]; ctype = d[9]; interlace = d[12];
             have_ihdr = true;
         } else if (!memcmp(type, "PLTE", 4)) plte.assign(d, d + len);
         else if (!memcmp(type, "tRNS", 4)) trns.assign(d, d + len);
@@ -166,14 +173,26 @@ bool load_png(const std::string& path, int req_channels, bool flip, std::vector<
         z_stream zs;
         memset(&zs, 0, sizeof zs);
         if (inflateInit(&zs) != Z_OK) { err = "zlib init failed"; return false; }
-        zs.next_in = idat.data();
-        zs.avail_in = (uInt)idat.size();
-        // upper bound: every pass row carries a filter byte
+        // upper bound: every pass row carries a filter byte (at most 2^15 x 2^15 x 4 + rows: 4 GiB + a little, so both
+        // sides are fed to zlib in pieces that fit its 32-bit counters)
         raw.resize((size_t)h * ((size_t)w * chans + 1) + 7 * (size_t)(h + 8) + 64);
-        zs.next_out = raw.data();
-        zs.avail_out = (uInt)raw.size();
-        int rc = inflate(&zs, Z_FINISH);
-        size_t got = raw.size() - zs.avail_out;
+        const size_t piece = (size_t)1 << 30;
+        size_t in_at = 0, out_at = 0;
+        int rc = Z_OK;
+        while (rc == Z_OK) {
+            if (zs.avail_in == 0 && in_at < idat.size()) {
+                const size_t n_in = std::min(piece, idat.size() - in_at);
+                zs.next_in = idat.data() + in_at; zs.avail_in = (uInt)n_in; in_at += n_in;
+            }
+            if (zs.avail_out == 0 && out_at < raw.size()) {
+                const size_t n_out = std::min(piece, raw.size() - out_at);
+                zs.next_out = raw.data() + out_at; zs.avail_out = (uInt)n_out; out_at += n_out;
+            }
+            if (zs.avail_out == 0) break;                          // more data than the header announced
+            rc = inflate(&zs, Z_NO_FLUSH);
+            if (rc == Z_BUF_ERROR && zs.avail_in == 0 && in_at == idat.size()) break;   // the stream ends early
+        }
+        const size_t got = out_at - zs.avail_out;
         inflateEnd(&zs);
         if (rc != Z_STREAM_END && rc != Z_OK && rc != Z_BUF_ERROR) { err = "zlib inflate failed on " + path; return false; }
         raw.resize(got);

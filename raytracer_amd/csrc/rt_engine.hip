@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -36,6 +37,7 @@ using namespace rtd;
 namespace {
 
 constexpr int IBLOCK = 512;         // intersect: 8 waves per block; two blocks per CU, each with its own copy of the scene in LDS
+constexpr int MAX_STAGED_BYTES = 80 * 1024;   // largest scene copy a block keeps in LDS (two blocks share a CU's 160 KiB)
 // Reservation counters of the intersect passes: the queue of a pass is cut into NCUR ranges with a counter each (a single
 // counter would take every reservation of the grid, and additions to one address are served one after another); the
 // counters of a pass lie CUR_STRIDE words apart so that they fall into different memory channels.
@@ -553,6 +555,25 @@ int fail(int code, const std::string& msg) { rt::set_error(msg); return code; }
         if (e_ != hipSuccess) return fail(RT_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));     \
     } while (0)
 
+// A device allocation that goes back when the scope ends, whichever way it ends.
+struct DevBuf {
+    void* p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) {
+        HIP_TRY(hipMalloc(&p, bytes ? bytes : 16));
+        return RT_OK;
+    }
+    int from_host(const void* src, size_t bytes) {
+        if (int rc = alloc(bytes)) return rc;
+        if (bytes) HIP_TRY(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+        return RT_OK;
+    }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
 template <typename T>
 int upload(T** dst, const void* src, size_t bytes) {
     *dst = nullptr;
@@ -566,6 +587,7 @@ int upload(T** dst, const void* src, size_t bytes) {
 struct rt_engine {
     rt_config cfg;
     hipStream_t stream = nullptr;
+    hipStream_t last_stream = nullptr;  // the stream of the latest render / assemble when the caller brought its own
     Scene sc{};
     bool have_scene = false, have_camera = false;
     Cam cam{};
@@ -683,6 +705,14 @@ int run_passes(rt_engine* e, const Batch& bt, hipStream_t st, uint32_t* counts, 
 
 int init_engine(rt_engine* e, const rt_config* cfg);
 
+// Wait for everything the engine has queued: its own stream and, when the latest render or assemble ran on a stream the
+// caller brought, that stream.
+int wait_all(rt_engine* e) {
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->last_stream) HIP_TRY(hipStreamSynchronize(e->last_stream));
+    return RT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -696,7 +726,8 @@ int rt_engine_create(const rt_config* cfg, rt_engine** out) {
     HIP_TRY(hipGetDeviceCount(&n_dev));
     if (cfg->device < 0 || cfg->device >= n_dev) return fail(RT_E_DEVICE, "no such HIP device");
     HIP_TRY(hipSetDevice(cfg->device));
-    rt_engine* e = new rt_engine();
+    rt_engine* e = new (std::nothrow) rt_engine();
+    if (!e) return fail(RT_E_NOMEM, "out of host memory");
     const int rc = init_engine(e, cfg);
     if (rc != RT_OK) { rt_engine_destroy(e); return rc; }    // whatever was allocated before the failure goes back
     *out = e;
@@ -738,6 +769,16 @@ int init_engine(rt_engine* e, const rt_config* cfg) {
     HIP_TRY(hipMalloc((void**)&e->d_frame, (size_t)cfg->width * cfg->height * 4));
     HIP_TRY(hipMemset(e->d_frame, 0, (size_t)cfg->width * cfg->height * 4));
     e->n_counts = cfg->bounces + 2;
+    // pass counters for the largest number of batches a render can need (one rank rendering the whole frame), so that
+    // rendering never allocates
+    e->counts_capacity = (int)((frame_paths / spp + batch_pixels - 1) / batch_pixels) * COUNT_WORDS;
+    HIP_TRY(hipMalloc((void**)&e->d_counts_all, sizeof(uint32_t) * (size_t)e->counts_capacity));
+    // the staged variants of the intersect kernel may use up to a whole CU's LDS; the limit is a property of the kernel,
+    // not of an engine or a scene, so every engine sets the same value
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
 #ifdef RT_PROFILE
     HIP_TRY(hipMalloc((void**)&e->dbg.prof, sizeof(unsigned long long) * 16 * 16));
     HIP_TRY(hipMemset(e->dbg.prof, 0, sizeof(unsigned long long) * 16 * 16));
@@ -759,7 +800,7 @@ extern "C" {
 void rt_engine_destroy(rt_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->cfg.device);
-    (void)hipStreamSynchronize(e->stream);
+    (void)wait_all(e);
     free_scene(e);
     for (int k = 0; k < 2; k++) { (void)hipFree(e->q.a[k]); (void)hipFree(e->q.b[k]); }
     (void)hipFree(e->q.hit); (void)hipFree(e->q.hit_ctr);
@@ -776,19 +817,21 @@ int rt_engine_get_config(const rt_engine* e, rt_config* out) {
     return RT_OK;
 }
 
-int rt_engine_set_scene(rt_engine* e, const rt_scene* s) {
+static int rt_engine_set_scene_impl(rt_engine* e, const rt_scene* s) {
     if (!e) return fail(RT_E_INVALID, "null engine");
     const rt_scene_flat* f = rt_scene_get_flat(s);
     if (!f) return fail(RT_E_INVALID, "scene is not built");
     HIP_TRY(hipSetDevice(e->cfg.device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (int rc = wait_all(e)) return rc;
     free_scene(e);
     Scene sc{};
     float4 *ent, *tris, *inst, *objects, *planes;
     rt::ImageRec* images;
     uint8_t* texels;
     // device entries (layout: rt_flat.h), 8 dwords each
-    if (f->ent_lo.size() > rt::SK_MASK || f->objects.size() / rt::RT_OBJ_F4 > rt::SK_MASK) return fail(RT_E_INVALID, "scene too large: more than 2^28 entries or objects");
+    // the traversal addresses entries with 32-bit byte offsets (32 bytes each) and texels with 32-bit offsets
+    if (f->ent_lo.size() >= (1u << 27) || f->objects.size() / rt::RT_OBJ_F4 > rt::SK_MASK) return fail(RT_E_INVALID, "scene too large: 2^27 entries or more, or more than 2^28 objects");
+    if (f->texels.size() >= ((size_t)1 << 32)) return fail(RT_E_INVALID, "scene too large: 4 GiB of texels or more");
     std::vector<rt::F4> inter(f->ent_lo.size() * 2);
     bool has_fog = false;
     for (size_t i = 0; i < f->ent_lo.size(); i++) {
@@ -887,13 +930,7 @@ int rt_engine_set_scene(rt_engine* e, const rt_scene* s) {
     e->sc = sc;
     // stage the whole scene in LDS when two 512-thread blocks per CU can each hold it (160 KiB per CU)
     const size_t need = (inter.size() + f->tris.size() + f->inst.size() + f->planes.size()) * 16;
-    e->staged_bytes = need <= 80 * 1024 ? need : 0;
-    if (e->staged_bytes) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->staged_bytes));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->staged_bytes));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->staged_bytes));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->staged_bytes));
-    }
+    e->staged_bytes = need <= (size_t)MAX_STAGED_BYTES ? need : 0;
     e->have_scene = true;
     return RT_OK;
 }
@@ -923,7 +960,11 @@ int rt_engine_render(rt_engine* e, uint32_t seed, int rank, int n_ranks, uint8_t
     if (!e->have_scene || !e->have_camera) return fail(RT_E_INVALID, "set a scene and a camera before rendering");
     if (n_ranks <= 0 || rank < 0 || rank >= n_ranks) return fail(RT_E_INVALID, "rank must be within [0, n_ranks)");
     HIP_TRY(hipSetDevice(e->cfg.device));
+    // the engine's own frame buffer holds width * height pixels; a rank's packed tiles can be more (partial tiles are
+    // padded to whole ones), so a split render must be given its destination
+    if (n_ranks > 1 && !d_rgba) return fail(RT_E_INVALID, "a render split across ranks needs d_rgba (rt_engine_tile_bytes() bytes)");
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    e->last_stream = stream ? (hipStream_t)stream : nullptr;
     uint8_t* out = d_rgba ? d_rgba : e->d_frame;
     const rt_config& c = e->cfg;
     const Cfg g = make_cfg(c);
@@ -933,11 +974,7 @@ int rt_engine_render(rt_engine* e, uint32_t seed, int rank, int n_ranks, uint8_t
     const int batch_pixels = e->q.capacity / spp;
     const int n_batches = (int)((my_pixels + batch_pixels - 1) / batch_pixels);
     const int per_batch = COUNT_WORDS;
-    if (n_batches * per_batch > e->counts_capacity) {
-        (void)hipFree(e->d_counts_all);
-        e->counts_capacity = n_batches * per_batch;
-        HIP_TRY(hipMalloc((void**)&e->d_counts_all, sizeof(uint32_t) * (size_t)e->counts_capacity));
-    }
+    if (n_batches * per_batch > e->counts_capacity) return fail(RT_E_INVALID, "render needs more batches than the engine was created for");
     HIP_TRY(hipMemsetAsync(e->d_counts_all, 0, sizeof(uint32_t) * (size_t)n_batches * per_batch, st));
     if (n_ranks > 1) HIP_TRY(hipMemsetAsync(out, 0, (size_t)my_pixels * 4, st));
     e->ev_used = 0;
@@ -973,6 +1010,7 @@ int rt_engine_assemble(rt_engine* e, const uint8_t* d_gathered, int n_ranks, uin
     if (!e || !d_gathered || n_ranks <= 0) return fail(RT_E_INVALID, "bad arguments");
     HIP_TRY(hipSetDevice(e->cfg.device));
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    e->last_stream = stream ? (hipStream_t)stream : nullptr;
     uint8_t* out = d_rgba ? d_rgba : e->d_frame;
     const long long per_rank = rt_engine_tile_bytes(e, n_ranks) / 4;
     const long long total = per_rank * n_ranks;
@@ -986,23 +1024,25 @@ int rt_engine_assemble(rt_engine* e, const uint8_t* d_gathered, int n_ranks, uin
 int rt_engine_sync(rt_engine* e) {
     if (!e) return fail(RT_E_INVALID, "null engine");
     HIP_TRY(hipSetDevice(e->cfg.device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    return RT_OK;
+    return wait_all(e);
 }
 
 int rt_engine_poll(rt_engine* e) {
     if (!e) return fail(RT_E_INVALID, "null engine");
     HIP_TRY(hipSetDevice(e->cfg.device));
-    const hipError_t rc = hipStreamQuery(e->stream);
-    if (rc == hipErrorNotReady) return 0;
-    HIP_TRY(rc);
+    for (hipStream_t st : {e->stream, e->last_stream}) {
+        if (st == nullptr) continue;
+        const hipError_t rc = hipStreamQuery(st);
+        if (rc == hipErrorNotReady) return 0;
+        HIP_TRY(rc);
+    }
     return 1;
 }
 
 int rt_engine_read_frame(rt_engine* e, uint8_t* rgba_out) {
     if (!e || !rgba_out) return fail(RT_E_INVALID, "null argument");
     HIP_TRY(hipSetDevice(e->cfg.device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (int rc = wait_all(e)) return rc;
     HIP_TRY(hipMemcpy(rgba_out, e->d_frame, (size_t)e->cfg.width * e->cfg.height * 4, hipMemcpyDeviceToHost));
     return RT_OK;
 }
@@ -1010,7 +1050,7 @@ int rt_engine_read_frame(rt_engine* e, uint8_t* rgba_out) {
 int rt_engine_keep_samples(rt_engine* e, int enable) {
     if (!e) return fail(RT_E_INVALID, "null engine");
     HIP_TRY(hipSetDevice(e->cfg.device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (int rc = wait_all(e)) return rc;
     if (enable && !e->dbg.primary_id) {
         const size_t cap = (size_t)e->q.capacity;
         HIP_TRY(hipMalloc((void**)&e->dbg.primary_id, cap * 4));
@@ -1024,10 +1064,10 @@ int rt_engine_keep_samples(rt_engine* e, int enable) {
     return RT_OK;
 }
 
-int rt_engine_read_samples(rt_engine* e, float* radiance3, int32_t* primary_id, float* primary_t, uint32_t* rng_draws) {
+static int rt_engine_read_samples_impl(rt_engine* e, float* radiance3, int32_t* primary_id, float* primary_t, uint32_t* rng_draws) {
     if (!e) return fail(RT_E_INVALID, "null engine");
     HIP_TRY(hipSetDevice(e->cfg.device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (int rc = wait_all(e)) return rc;
     if (!e->dbg.primary_id) return fail(RT_E_INVALID, "per-sample outputs are off: call rt_engine_keep_samples(e, 1) before rendering");
     if (!e->debug_valid) return fail(RT_E_INVALID, "per-sample outputs need a single-rank render that fits one batch");
     const rt_config& c = e->cfg;
@@ -1064,6 +1104,7 @@ int rt_engine_trace(rt_engine* e, int n, const float* o3, const float* d3, int32
     if (!e->have_scene) return fail(RT_E_INVALID, "no scene set");
     if (n == 0) return RT_OK;
     HIP_TRY(hipSetDevice(e->cfg.device));
+    if (int rc = wait_all(e)) return rc;
     float *d_o = nullptr, *d_d = nullptr, *d_rec = nullptr;
     int32_t* d_hit = nullptr;
     int rc = RT_OK;
@@ -1084,13 +1125,14 @@ int rt_engine_trace(rt_engine* e, int n, const float* o3, const float* d3, int32
     return rc;
 }
 
-int rt_engine_ray_color(rt_engine* e, int n, const float* o3, const float* d3, int bounces, const uint32_t* keys, float* rgb3) {
+static int rt_engine_ray_color_impl(rt_engine* e, int n, const float* o3, const float* d3, int bounces, const uint32_t* keys, float* rgb3) {
     if (!e || !o3 || !d3 || !keys || !rgb3 || n < 0) return fail(RT_E_INVALID, "bad arguments");
     if (!e->have_scene) return fail(RT_E_INVALID, "no scene set");
     if (bounces < 0 || bounces > e->cfg.bounces) return fail(RT_E_INVALID, "bounces must be within the engine's configured bounce count");
     if (n > e->q.capacity) return fail(RT_E_INVALID, "more rays than the batch capacity");
     if (n == 0) return RT_OK;
     HIP_TRY(hipSetDevice(e->cfg.device));
+    if (int rc = wait_all(e)) return rc;   // the queues may still belong to a render on a stream the caller brought
     float *d_o = nullptr, *d_d = nullptr;
     uint32_t *d_keys = nullptr, *d_counts = nullptr;
     int rc = RT_OK;
@@ -1125,10 +1167,10 @@ int rt_engine_ray_color(rt_engine* e, int n, const float* o3, const float* d3, i
     return rc;
 }
 
-int rt_engine_get_stats(rt_engine* e, rt_stats* out) {
+static int rt_engine_get_stats_impl(rt_engine* e, rt_stats* out) {
     if (!e || !out) return fail(RT_E_INVALID, "null argument");
     HIP_TRY(hipSetDevice(e->cfg.device));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (int rc = wait_all(e)) return rc;
     memset(out, 0, sizeof *out);
     const int nb = e->last_batches, nc = e->n_counts, per_batch = COUNT_WORDS;
     if (nb <= 0) return RT_OK;
@@ -1182,57 +1224,59 @@ int rt_engine_kernel_times(rt_engine* e, double out2[2]) {
 int rt_engine_eval_math(rt_engine* e, int n, const float* x, const float* y, float* sin_x, float* atan2_yx) {
     if (!e || !x || !y || !sin_x || !atan2_yx || n <= 0) return fail(RT_E_INVALID, "bad arguments");
     HIP_TRY(hipSetDevice(e->cfg.device));
-    float *dx, *dy, *ds, *da;
-    if (int rc = upload(&dx, x, (size_t)n * 4)) return rc;
-    if (int rc = upload(&dy, y, (size_t)n * 4)) return rc;
-    HIP_TRY(hipMalloc((void**)&ds, (size_t)n * 4));
-    HIP_TRY(hipMalloc((void**)&da, (size_t)n * 4));
-    hipLaunchKernelGGL(math_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, dx, dy, ds, da);
+    DevBuf dx, dy, ds, da;
+    if (int rc = dx.from_host(x, (size_t)n * 4)) return rc;
+    if (int rc = dy.from_host(y, (size_t)n * 4)) return rc;
+    if (int rc = ds.alloc((size_t)n * 4)) return rc;
+    if (int rc = da.alloc((size_t)n * 4)) return rc;
+    hipLaunchKernelGGL(math_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, dx.as<float>(), dy.as<float>(), ds.as<float>(), da.as<float>());
     HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipMemcpy(sin_x, ds, (size_t)n * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(atan2_yx, da, (size_t)n * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(dx); (void)hipFree(dy); (void)hipFree(ds); (void)hipFree(da);
+    HIP_TRY(hipMemcpy(sin_x, ds.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(atan2_yx, da.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 int rt_engine_eval_rng(rt_engine* e, int n, const uint32_t* key, const uint32_t* ctr, uint32_t* r31, float* ud) {
     if (!e || !key || !ctr || !r31 || !ud || n <= 0) return fail(RT_E_INVALID, "bad arguments");
     HIP_TRY(hipSetDevice(e->cfg.device));
-    uint32_t *dk, *dc, *dr;
-    float* du;
-    if (int rc = upload(&dk, key, (size_t)n * 4)) return rc;
-    if (int rc = upload(&dc, ctr, (size_t)n * 4)) return rc;
-    HIP_TRY(hipMalloc((void**)&dr, (size_t)n * 4));
-    HIP_TRY(hipMalloc((void**)&du, (size_t)n * 4));
-    hipLaunchKernelGGL(rng_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, dk, dc, dr, du);
+    DevBuf dk, dc, dr, du;
+    if (int rc = dk.from_host(key, (size_t)n * 4)) return rc;
+    if (int rc = dc.from_host(ctr, (size_t)n * 4)) return rc;
+    if (int rc = dr.alloc((size_t)n * 4)) return rc;
+    if (int rc = du.alloc((size_t)n * 4)) return rc;
+    hipLaunchKernelGGL(rng_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, dk.as<uint32_t>(), dc.as<uint32_t>(), dr.as<uint32_t>(), du.as<float>());
     HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipMemcpy(r31, dr, (size_t)n * 4, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(ud, du, (size_t)n * 4, hipMemcpyDeviceToHost));
-    (void)hipFree(dk); (void)hipFree(dc); (void)hipFree(dr); (void)hipFree(du);
+    HIP_TRY(hipMemcpy(r31, dr.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(ud, du.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return RT_OK;
 }
 // The slab test's reciprocal-based division against the hardware's IEEE division: the n given pairs plus
 // threads x rounds x 4 generated pairs next to rounding boundaries.  out[0] = disagreeing pairs; first_bad4 = (a, b, got, want).
 int rt_engine_check_division(rt_engine* e, int n, const float* a, const float* b, uint32_t seed, int threads, int rounds,
                              uint64_t* mismatches, float* first_bad4) {
-    if (!e || !mismatches || !first_bad4 || n < 0 || threads <= 0 || rounds < 0) return fail(RT_E_INVALID, "bad arguments");
+    if (!e || !mismatches || !first_bad4 || n < 0 || threads <= 0 || rounds < 0 || (n > 0 && (!a || !b))) return fail(RT_E_INVALID, "bad arguments");
     HIP_TRY(hipSetDevice(e->cfg.device));
-    float *da = nullptr, *db = nullptr, *dbad;
-    unsigned long long* dm;
-    if (int rc = upload(&da, a, (size_t)n * 4)) return rc;
-    if (int rc = upload(&db, b, (size_t)n * 4)) return rc;
-    HIP_TRY(hipMalloc((void**)&dm, 16));
-    HIP_TRY(hipMalloc((void**)&dbad, 16));
-    HIP_TRY(hipMemset(dm, 0, 16));
-    HIP_TRY(hipMemset(dbad, 0, 16));
+    DevBuf da, db, dm, dbad;
+    if (int rc = da.from_host(a, (size_t)n * 4)) return rc;
+    if (int rc = db.from_host(b, (size_t)n * 4)) return rc;
+    if (int rc = dm.alloc(16)) return rc;
+    if (int rc = dbad.alloc(16)) return rc;
+    HIP_TRY(hipMemset(dm.p, 0, 16));
+    HIP_TRY(hipMemset(dbad.p, 0, 16));
     const int total = std::max(n, threads);
-    hipLaunchKernelGGL(div_check_kernel, dim3((total + 255) / 256), dim3(256), 0, e->stream, n, da, db, seed, rounds, dm, dbad);
+    hipLaunchKernelGGL(div_check_kernel, dim3((total + 255) / 256), dim3(256), 0, e->stream, n, da.as<float>(), db.as<float>(), seed, rounds,
+                       dm.as<unsigned long long>(), dbad.as<float>());
     HIP_TRY(hipStreamSynchronize(e->stream));
     unsigned long long m[2];
-    HIP_TRY(hipMemcpy(m, dm, 16, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(first_bad4, dbad, 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(m, dm.p, 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(first_bad4, dbad.p, 16, hipMemcpyDeviceToHost));
     *mismatches = m[0];
-    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dm); (void)hipFree(dbad);
     return RT_OK;
 }
+
+// The entry points above that allocate host memory, behind rt::guard: no exception crosses the C boundary.
+int rt_engine_set_scene(rt_engine* e, const rt_scene* s) { return rt::guard([&] { return rt_engine_set_scene_impl(e, s); }); }
+int rt_engine_read_samples(rt_engine* e, float* radiance3, int32_t* primary_id, float* primary_t, uint32_t* rng_draws) { return rt::guard([&] { return rt_engine_read_samples_impl(e, radiance3, primary_id, primary_t, rng_draws); }); }
+int rt_engine_ray_color(rt_engine* e, int n, const float* o3, const float* d3, int bounces, const uint32_t* keys, float* rgb3) { return rt::guard([&] { return rt_engine_ray_color_impl(e, n, o3, d3, bounces, keys, rgb3); }); }
+int rt_engine_get_stats(rt_engine* e, rt_stats* out) { return rt::guard([&] { return rt_engine_get_stats_impl(e, out); }); }
 
 }  // extern "C"

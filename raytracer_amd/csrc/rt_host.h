@@ -2,6 +2,8 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -38,6 +40,16 @@ inline uint32_t fmix32(uint32_t x) {
 inline uint32_t rand31(uint32_t key, uint32_t ctr) { return fmix32(key ^ (ctr * 0x9E3779B9u)) >> 1; }
 
 void set_error(const std::string& msg);
+
+// No exception may cross the C boundary: entry points whose work allocates host memory run it through guard(), which
+// turns std::bad_alloc into RT_E_NOMEM (-4) and anything else into RT_E_INVALID (-1) with the message in rt_last_error().
+template <typename F>
+int guard(F&& body) noexcept {
+    try { return body(); }
+    catch (const std::bad_alloc&) { set_error("out of host memory"); return -4; }
+    catch (const std::exception& ex) { set_error(std::string("unexpected error: ") + ex.what()); return -1; }
+    catch (...) { set_error("unexpected error"); return -1; }
+}
 
 bool load_obj(const std::string& path, std::vector<float>& verts8, std::string& err);
 bool load_png(const std::string& path, int req_channels, bool flip, std::vector<uint8_t>& out, int& w, int& h,

@@ -390,14 +390,14 @@ int rt_scene_add_texture_checker(rt_scene* s, const float a[3], const float b[3]
     s->texs.push_back({RT_TEX_CHECKER, {a[0], a[1], a[2]}, {b[0], b[1], b[2]}, -1});
     return (int)s->texs.size() - 1;
 }
-int rt_scene_add_texture_image(rt_scene* s, const uint8_t* rgba, int w, int h) {
+static int rt_scene_add_texture_image_impl(rt_scene* s, const uint8_t* rgba, int w, int h) {
     if (!s || !rgba || w <= 0 || h <= 0) return fail(RT_E_INVALID, "bad image texture arguments");
     Image im{std::vector<uint8_t>(rgba, rgba + (size_t)w * h * 4), w, h, 4};
     s->images.push_back(std::move(im));
     s->texs.push_back({RT_TEX_IMAGE, {0, 0, 0}, {0, 0, 0}, (int)s->images.size() - 1});
     return (int)s->texs.size() - 1;
 }
-int rt_scene_add_texture_file(rt_scene* s, const char* path) {
+static int rt_scene_add_texture_file_impl(rt_scene* s, const char* path) {
     if (!s || !path) return fail(RT_E_INVALID, "null argument");
     std::vector<uint8_t> px;
     int w, h, fc;
@@ -444,7 +444,7 @@ int rt_scene_add_plane(rt_scene* s, float y, int material) {
     s->planes.push_back((int)s->objs.size() - 1);
     return o.id;
 }
-int rt_scene_add_mesh(rt_scene* s, const float* verts8, int n_tri, float size, int material, int rot_axis, float degrees,
+static int rt_scene_add_mesh_impl(rt_scene* s, const float* verts8, int n_tri, float size, int material, int rot_axis, float degrees,
                       int has_move, const float offset[3]) {
     if (int rc = check_material(s, material)) return rc;
     if (!verts8 || n_tri <= 0) return fail(RT_E_INVALID, "mesh has no triangles");
@@ -503,7 +503,7 @@ int rt_scene_add_fog(rt_scene* s, const float center[3], float radius, float den
     s->top.push_back(cur);
     return id;
 }
-int rt_scene_add_mesh_file(rt_scene* s, const char* path, float size, int material, int rot_axis, float degrees, int has_move,
+static int rt_scene_add_mesh_file_impl(rt_scene* s, const char* path, float size, int material, int rot_axis, float degrees, int has_move,
                            const float offset[3]) {
     if (!path) return fail(RT_E_INVALID, "null path");
     std::vector<float> v;
@@ -512,13 +512,13 @@ int rt_scene_add_mesh_file(rt_scene* s, const char* path, float size, int materi
     if (v.size() % 24 != 0 || v.empty()) return fail(RT_E_IO, std::string("Vertex count was not a multiple of 3: ") + path);
     return rt_scene_add_mesh(s, v.data(), (int)v.size() / 24, size, material, rot_axis, degrees, has_move, offset);
 }
-int rt_scene_set_skybox(rt_scene* s, const uint8_t* rgb, int w, int h) {
+static int rt_scene_set_skybox_impl(rt_scene* s, const uint8_t* rgb, int w, int h) {
     if (!s || !rgb || w <= 0 || h <= 0) return fail(RT_E_INVALID, "bad skybox arguments");
     if (s->built) return fail(RT_E_INVALID, "scene is already built");
     s->sky = Image{std::vector<uint8_t>(rgb, rgb + (size_t)w * h * 3), w, h, 3};
     return RT_OK;
 }
-int rt_scene_set_skybox_file(rt_scene* s, const char* path) {
+static int rt_scene_set_skybox_file_impl(rt_scene* s, const char* path) {
     if (!s || !path) return fail(RT_E_INVALID, "null argument");
     std::vector<uint8_t> px;
     int w, h, fc;
@@ -531,7 +531,7 @@ int rt_scene_set_skybox_file(rt_scene* s, const char* path) {
 // The alternative scene the reference keeps behind "#else" (World.cpp:34-40): a room of four slabs, an emissive sphere that
 // moves with `time`, a fog volume rotated about X, and the checkered metal plane (World.cpp:17).  The light's x is
 // "3 * sin(time * 0.1f)": the unqualified sin takes the double overload, and the product narrows into the vec3.
-int rt_scene_add_alt_objects(rt_scene* s, const char* asset_dir, float time) {
+static int rt_scene_add_alt_objects_impl(rt_scene* s, const char* asset_dir, float time) {
     if (!s || !asset_dir) return fail(RT_E_INVALID, "null argument");
     const std::string dir = std::string(asset_dir) + "/src/stb_image/";
     if (int rc = rt_scene_set_skybox_file(s, (dir + "skybox12.png").c_str())) return rc;   // World.cpp:49
@@ -554,7 +554,7 @@ int rt_scene_add_alt_objects(rt_scene* s, const char* asset_dir, float time) {
 }
 
 // World.cpp:15-32.  `time` only matters to the alternative scene of World.cpp:34-40, which the reference compiles out.
-int rt_scene_add_default_objects(rt_scene* s, const char* asset_dir, float time) {
+static int rt_scene_add_default_objects_impl(rt_scene* s, const char* asset_dir, float time) {
     (void)time;
     if (!s || !asset_dir) return fail(RT_E_INVALID, "null argument");
     const std::string dir = std::string(asset_dir) + "/src/stb_image/";
@@ -584,7 +584,7 @@ int rt_scene_add_default_objects(rt_scene* s, const char* asset_dir, float time)
     return RT_OK;
 }
 
-int rt_scene_build(rt_scene* s, uint32_t build_key) {
+static int rt_scene_build_impl(rt_scene* s, uint32_t build_key) {
     if (!s) return fail(RT_E_INVALID, "null scene");
     if (s->built) return fail(RT_E_INVALID, "scene is already built");
     if (s->top.empty()) return fail(RT_E_INVALID, "scene has no bounded objects");
@@ -708,7 +708,7 @@ int rt_scene_flat_info(const rt_scene* s, int64_t out[7]) {
     return RT_OK;
 }
 
-int rt_load_obj(const char* path, int max_verts, float* verts8) {
+static int rt_load_obj_impl(const char* path, int max_verts, float* verts8) {
     if (!path) return fail(RT_E_INVALID, "null path");
     std::vector<float> v;
     std::string err;
@@ -718,7 +718,7 @@ int rt_load_obj(const char* path, int max_verts, float* verts8) {
     if (verts8) memcpy(verts8, v.data(), v.size() * sizeof(float));
     return n;
 }
-int rt_load_png(const char* path, int channels, int flip, int64_t max_bytes, uint8_t* out, int32_t* w, int32_t* h, int32_t* file_channels) {
+static int rt_load_png_impl(const char* path, int channels, int flip, int64_t max_bytes, uint8_t* out, int32_t* w, int32_t* h, int32_t* file_channels) {
     if (!path || !w || !h || !file_channels) return fail(RT_E_INVALID, "null argument");
     std::vector<uint8_t> px;
     std::string err;
@@ -753,5 +753,20 @@ void rt_camera_input(float cam[12], float xrel, float yrel, int key_w, int key_a
     if (key_s) pos = pos - df * speed;
     cam[0] = pos.x; cam[1] = pos.y; cam[2] = pos.z;
 }
+
+// The entry points above that allocate host memory, behind rt::guard: no exception crosses the C boundary.
+int rt_scene_add_texture_image(rt_scene* s, const uint8_t* rgba, int w, int h) { return guard([&] { return rt_scene_add_texture_image_impl(s, rgba, w, h); }); }
+int rt_scene_add_texture_file(rt_scene* s, const char* path) { return guard([&] { return rt_scene_add_texture_file_impl(s, path); }); }
+int rt_scene_add_mesh(rt_scene* s, const float* verts8, int n_tri, float size, int material, int rot_axis, float degrees,
+                      int has_move, const float offset[3]) { return guard([&] { return rt_scene_add_mesh_impl(s, verts8, n_tri, size, material, rot_axis, degrees, has_move, offset); }); }
+int rt_scene_add_mesh_file(rt_scene* s, const char* path, float size, int material, int rot_axis, float degrees, int has_move,
+                           const float offset[3]) { return guard([&] { return rt_scene_add_mesh_file_impl(s, path, size, material, rot_axis, degrees, has_move, offset); }); }
+int rt_scene_set_skybox(rt_scene* s, const uint8_t* rgb, int w, int h) { return guard([&] { return rt_scene_set_skybox_impl(s, rgb, w, h); }); }
+int rt_scene_set_skybox_file(rt_scene* s, const char* path) { return guard([&] { return rt_scene_set_skybox_file_impl(s, path); }); }
+int rt_scene_add_alt_objects(rt_scene* s, const char* asset_dir, float time) { return guard([&] { return rt_scene_add_alt_objects_impl(s, asset_dir, time); }); }
+int rt_scene_add_default_objects(rt_scene* s, const char* asset_dir, float time) { return guard([&] { return rt_scene_add_default_objects_impl(s, asset_dir, time); }); }
+int rt_scene_build(rt_scene* s, uint32_t build_key) { return guard([&] { return rt_scene_build_impl(s, build_key); }); }
+int rt_load_obj(const char* path, int max_verts, float* verts8) { return guard([&] { return rt_load_obj_impl(path, max_verts, verts8); }); }
+int rt_load_png(const char* path, int channels, int flip, int64_t max_bytes, uint8_t* out, int32_t* w, int32_t* h, int32_t* file_channels) { return guard([&] { return rt_load_png_impl(path, channels, flip, max_bytes, out, w, h, file_channels); }); }
 
 }  // extern "C"

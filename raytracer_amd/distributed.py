@@ -28,18 +28,29 @@ class TileRenderer:
             self.mine = torch.zeros(self.nb, dtype=torch.uint8, device=self.device)
             self.gathered = torch.zeros(self.nb * world_size, dtype=torch.uint8, device=self.device) if rank == display_rank else None
 
+        # Render, gather and assemble are ordered by ONE explicit stream: the engine gets its handle (a null handle
+        # would mean "the engine's private stream", which torch knows nothing about), and the collective is issued with
+        # that stream current, so RCCL's own stream waits for the render and the assemble waits for the gather.
+        self.stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
+
     def _stream(self):
-        return torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else None
+        return self.stream.cuda_stream if self.stream is not None else None
 
     def render_frame(self, seed):
         """Enqueue one frame.  Returns the frame tensor (H*W*4 bytes) on the display rank, None elsewhere."""
+        if self.stream is None:
+            return self._render_frame(seed)
+        with torch.cuda.stream(self.stream):
+            return self._render_frame(seed)
+
+    def _render_frame(self, seed):
         st = self._stream()
         if self.world == 1:
             self.e.render(seed, 0, 1, self.frame.data_ptr(), st)
             return self.frame
         self.e.render(seed, self.rank, self.world, self.mine.data_ptr(), st)
         if self.via_host:
-            torch.cuda.current_stream(self.device).synchronize()
+            self.stream.synchronize()
             mine = self.mine.cpu()
             if self.rank == self.display:
                 parts = [torch.empty_like(mine) for _ in range(self.world)]

@@ -296,6 +296,19 @@ def test_batching_tiles_and_ranks_do_not_change_pixels(rt, gpu_default):
     assert_bits(small, base, "small batches")
     tiles = make_engine(rt, gpu_default, W, H, S, B, tile_w=16, tile_h=8, max_batch_paths=70000).render_frame(3)
     assert_bits(tiles, base, "16x8 tiles")
+    # a frame smaller than one row of tiles, split in two: each rank's packed buffer (one padded 64 x 64 tile) is larger
+    # than the frame itself
+    tiny = make_engine(rt, gpu_default, 65, 33, 2, 2)
+    tiny_base = tiny.render_frame(3)
+    nb = tiny.tile_bytes(2)
+    assert nb == 64 * 64 * 4 and 2 * nb > 65 * 33 * 4
+    gathered = torch.zeros(2 * nb, dtype=torch.uint8, device="cuda")
+    for r in range(2):
+        tiny.render(3, rank=r, n_ranks=2, d_out=gathered.data_ptr() + r * nb)
+    out = torch.zeros(33 * 65 * 4, dtype=torch.uint8, device="cuda")
+    tiny.assemble(gathered.data_ptr(), 2, d_out=out.data_ptr())
+    tiny.sync()
+    assert_bits(out.cpu().numpy().reshape(33, 65, 4), tiny_base, "65 x 33 frame, 2-rank tile split")
     for n_ranks in (2, 3, 8):
         e = make_engine(rt, gpu_default, W, H, S, B, tile_w=32, tile_h=32)
         nb = e.tile_bytes(n_ranks)
@@ -337,6 +350,8 @@ def test_error_behaviour(rt, gpu_default):
     e.set_camera(rt.camera_look(CAM_POS, CAM_LOOK))
     with pytest.raises(rt.RtError):
         e.render(1, rank=2, n_ranks=2)
+    with pytest.raises(rt.RtError, match="d_rgba"):
+        e.render(1, rank=0, n_ranks=2)   # a rank's padded tiles can be larger than the engine's own frame buffer
     with pytest.raises(rt.RtError):
         e.set_window((0, 0, 33, 10))
     with pytest.raises(rt.RtError):
