@@ -165,6 +165,14 @@ int rt_engine_read_samples(rt_engine* e, float* radiance3, int32_t* primary_id, 
  * hit_id: object id or -1.  rec9: distance, point[3], normal[3], uv[2]; for a miss distance holds what the reference's
  * HitInfo.distance holds (FLT_MAX or a stale value, Object.cpp:17-19,534-550). */
 int rt_engine_trace(rt_engine* e, int n, const float* origins3, const float* dirs3, int32_t* hit_id, float* rec9);
+/* rt_engine_trace for callers that cannot allocate device memory (code that runs under HIP graph capture elsewhere in the
+ * process, tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments and
+ * results as rt_engine_trace, at most RT_TRACE_STATIC_MAX_RAYS rays per call (more: RT_E_INVALID).  The rays and results
+ * are staged in a static 2 MiB device array that every GPU the library runs on holds until the process ends; calls on
+ * the same GPU share it, so calls that overlap on one GPU (from several engines or threads) race and must be serialised
+ * by the caller.  Calls no hipMalloc / hipFree and no allocating library routine. */
+#define RT_TRACE_STATIC_MAX_RAYS 32768
+int rt_engine_trace_static(rt_engine* e, int n, const float* origins3, const float* dirs3, int32_t* hit_id, float* rec9);
 /* World::GetRayColor (World.cpp:104-171) for arbitrary rays, one RNG key per ray. */
 int rt_engine_ray_color(rt_engine* e, int n, const float* origins3, const float* dirs3, int bounces, const uint32_t* keys, float* rgb3);
 

@@ -34,6 +34,13 @@
 
 using namespace rtd;
 
+// Staging memory of rt_engine_trace_static, the closest-hit query that allocates nothing: the rays' origins and
+// directions on the way in, hit ids and hit records on the way out, 64 bytes per ray.  One array per GPU the library
+// runs on, held until the process ends.  Host code never uses this name as an address: every engine asks the runtime
+// for its device's copy once (hipGetSymbolAddress in init_engine) and hands that pointer to copies and kernels.
+constexpr size_t TRACE_STATIC_BYTES_PER_RAY = 12 + 12 + 4 + 36;
+static __device__ __align__(256) unsigned char scratch[(size_t)RT_TRACE_STATIC_MAX_RAYS * TRACE_STATIC_BYTES_PER_RAY];
+
 namespace {
 
 constexpr int IBLOCK = 512;         // intersect: 8 waves per block; two blocks per CU, each with its own copy of the scene in LDS
@@ -588,6 +595,7 @@ struct rt_engine {
     rt_config cfg;
     hipStream_t stream = nullptr;
     hipStream_t last_stream = nullptr;  // the stream of the latest render / assemble when the caller brought its own
+    unsigned char* d_scratch = nullptr; // this device's copy of the static staging array (rt_engine_trace_static)
     Scene sc{};
     bool have_scene = false, have_camera = false;
     Cam cam{};
@@ -757,6 +765,8 @@ int init_engine(rt_engine* e, const rt_config* cfg) {
     HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
     e->n_cus = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreate(&e->stream));
+    // the engine's device is current (rt_engine_create): the address of this GPU's copy of the staging array
+    HIP_TRY(hipGetSymbolAddress((void**)&e->d_scratch, HIP_SYMBOL(scratch)));
     const size_t cap = (size_t)e->q.capacity;
     for (int k = 0; k < 2; k++) {
         HIP_TRY(hipMalloc((void**)&e->q.a[k], cap * sizeof(float4)));
@@ -1123,6 +1133,33 @@ int rt_engine_trace(rt_engine* e, int n, const float* o3, const float* d3, int32
     }
     (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_hit); (void)hipFree(d_rec);
     return rc;
+}
+
+// rt_engine_trace for callers that must not allocate: the rays and the results are staged in this GPU's static array
+// instead of four fresh allocations.  No hipMalloc / hipFree / allocating library call on this path.
+int rt_engine_trace_static(rt_engine* e, int n, const float* o3, const float* d3, int32_t* hit_id, float* rec9) {
+    if (!e || !o3 || !d3 || !hit_id || !rec9 || n < 0) return fail(RT_E_INVALID, "bad arguments");
+    if (!e->have_scene) return fail(RT_E_INVALID, "no scene set");
+    if (n > RT_TRACE_STATIC_MAX_RAYS) return fail(RT_E_INVALID, "rt_engine_trace_static takes at most RT_TRACE_STATIC_MAX_RAYS (32768) rays per call");
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    if (!e->d_scratch) return fail(RT_E_DEVICE, "the static staging array was not resolved on this device");
+    // fixed sections of the array, sized for the maximum: origins | directions | hit ids | records.  Every byte a call
+    // reads was written by the same call (inputs by the copies below, outputs by the kernel for rays 0..n-1), so what an
+    // earlier, larger call left behind is never looked at and nothing needs clearing.
+    unsigned char* base = e->d_scratch;
+    float* d_o = reinterpret_cast<float*>(base);
+    float* d_d = reinterpret_cast<float*>(base + (size_t)RT_TRACE_STATIC_MAX_RAYS * 12);
+    int32_t* d_hit = reinterpret_cast<int32_t*>(base + (size_t)RT_TRACE_STATIC_MAX_RAYS * 24);
+    float* d_rec = reinterpret_cast<float*>(base + (size_t)RT_TRACE_STATIC_MAX_RAYS * 28);
+    HIP_TRY(hipMemcpyAsync(d_o, o3, (size_t)n * 12, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(d_d, d3, (size_t)n * 12, hipMemcpyHostToDevice, e->stream));
+    hipLaunchKernelGGL(trace_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->sc, n, d_o, d_d, d_hit, d_rec);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(hit_id, d_hit, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(rec9, d_rec, (size_t)n * 36, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return RT_OK;
 }
 
 static int rt_engine_ray_color_impl(rt_engine* e, int n, const float* o3, const float* d3, int bounces, const uint32_t* keys, float* rgb3) {

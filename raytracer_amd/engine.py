@@ -14,6 +14,7 @@ ASSET_DIR = os.path.join(os.path.dirname(HERE), "assets")
 
 MAT_NONE, MAT_DIFFUSE, MAT_METAL, MAT_ISOTROPIC, MAT_LIGHT = 0, 1, 2, 3, 4
 TEX_COLOR, TEX_CHECKER, TEX_IMAGE = 0, 1, 2
+TRACE_STATIC_MAX_RAYS = 32768   # RT_TRACE_STATIC_MAX_RAYS
 
 f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
@@ -88,6 +89,7 @@ SIGNATURES = {
     "rt_engine_keep_samples": (C.c_int, [_V, C.c_int]),
     "rt_engine_read_samples": (C.c_int, [_V, _V, _V, _V, _V]),
     "rt_engine_trace": (C.c_int, [_V, C.c_int, f32p, f32p, i32p, f32p]),
+    "rt_engine_trace_static": (C.c_int, [_V, C.c_int, f32p, f32p, i32p, f32p]),
     "rt_engine_ray_color": (C.c_int, [_V, C.c_int, f32p, f32p, C.c_int, u32p, f32p]),
     "rt_engine_get_stats": (C.c_int, [_V, C.POINTER(Stats)]),
     "rt_engine_time_kernels": (C.c_int, [_V, C.c_int]),
@@ -386,6 +388,15 @@ class Engine:
         hit = np.zeros(len(o), np.int32)
         rec = np.zeros((len(o), 9), np.float32)
         _check(self.L.rt_engine_trace(self.h, len(o), o, d, hit, rec))
+        return hit, rec
+
+    def trace_static(self, o, d):
+        """trace() through the entry point that allocates nothing (at most TRACE_STATIC_MAX_RAYS rays)"""
+        o = np.ascontiguousarray(o, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(d, np.float32).reshape(-1, 3)
+        hit = np.zeros(len(o), np.int32)
+        rec = np.zeros((len(o), 9), np.float32)
+        _check(self.L.rt_engine_trace_static(self.h, len(o), o, d, hit, rec))
         return hit, rec
 
     def ray_color(self, o, d, bounces, keys):
