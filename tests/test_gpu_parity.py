@@ -524,3 +524,98 @@ def test_random_scenes_bit_exact(rt, orc, assets, seed):
     assert_bits(got["rng_draws"], ref["rng_draws"], f"random scene {seed}: RNG draws")
     assert_bits(got["radiance"], ref["radiance"], f"random scene {seed}: radiance")
     assert_bits(frame, ref["rgba"], f"random scene {seed}: frame")
+
+
+@pytest.fixture(scope="module")
+def c3_scene(rt, golden):
+    """the 100 000-primitive traversal-stress scene at its real size, built through the C ABI"""
+    import time
+    from raytracer_amd.synthetic import synthetic_scene
+    g = golden("scene_c3")
+    t0 = time.perf_counter()
+    scene = synthetic_scene(rt, int(g["n"]), int(g["build_key"]))
+    return scene, time.perf_counter() - t0
+
+
+def _sha(a):
+    import hashlib
+    return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+
+
+def test_c3_tree_is_the_reference_tree(rt, golden, c3_scene):
+    """BVH_Node::BVH_Node (Object.cpp:181-225) over 100 000 objects: boxes, links and leaf order of the tree the reference
+    built from the same list under the same key (digests of the whole arrays, every 1000th row for a readable failure)"""
+    g = golden("scene_c3")
+    scene, seconds = c3_scene
+    boxes, left, right, leaf = scene.dump_top()
+    assert len(left) == int(g["n_inner"])
+    for name, got in (("boxes", boxes), ("left", left), ("right", right), ("leaf_ids", leaf)):
+        assert_bits(got[::1000], g[f"top_{name}_rows"], f"C3 tree {name}, every 1000th row")
+        assert_bits(_sha(got), g[f"top_{name}_sha256"], f"C3 tree {name}, digest")
+    info = scene.flat_info()
+    assert info["entries"] > 2 * int(g["n"])            # too large for LDS: the traversal reads it from memory
+    print(f"C3 scene: {info['entries']} entries, built in {seconds:.2f} s (reference: {float(g['reference_build_seconds']):.1f} s)")
+
+
+def test_c3_map_and_crop_vs_reference(rt, orc, golden, assets, c3_scene):
+    """sample (0,0) of a 480 x 270 frame and a 32 x 32 crop of the 3840 x 2160, 256 spp frame: ids, distances and draw
+    counts equal the reference's bit for bit; radiance and colour equal the portable oracle's bit for bit"""
+    g = golden("scene_c3")
+    scene, _ = c3_scene
+    cam = rt.camera_look(g["cam_pos"], g["cam_look"])
+    seed = int(g["seed"])
+    Wm, Hm, Sm, Bm = (int(v) for v in g["map_cfg"])
+    e = make_engine(rt, scene, Wm, Hm, Sm, Bm, cam)
+    e.keep_samples(True)
+    e.render(seed)
+    got = e.read_samples(want=("primary_id", "primary_t"))
+    assert_bits(got["primary_id"].reshape(Hm, Wm), g["map_primary_id"], "C3 map ids vs the reference")
+    assert_bits(got["primary_t"].reshape(Hm, Wm), g["map_primary_t"], "C3 map distances vs the reference")
+    assert len(np.unique(g["map_primary_id"])) > 5000     # the map sees thousands of different objects
+    e.close()
+    W, H, S, B = (int(v) for v in g["cfg"])
+    rect = tuple(int(v) for v in g["crop"])
+    e = make_engine(rt, scene, W, H, S, B, cam, max_batch_paths=1 << 22)
+    e.keep_samples(True)
+    e.set_window(rect)
+    e.render(seed)
+    frame = e.read_frame()
+    got = e.read_samples()
+    x0, y0, x1, y1 = rect
+    assert_bits(got["primary_id"], g["crop_primary_id"], "C3 crop ids vs the reference")
+    assert_bits(got["primary_t"], g["crop_primary_t"], "C3 crop distances vs the reference")
+    assert_bits(got["rng_draws"].astype(np.uint16), g["crop_rng_draws"], "C3 crop RNG draws vs the reference")
+    assert_frame_close(frame[y0:y1, x0:x1], g["crop_rgba"], "C3 crop colour vs the reference")
+    sub = g["crop_radiance_pixels"]
+    same = np.all(got["radiance"][sub].view(np.uint32) == g["crop_radiance"].view(np.uint32), axis=2).mean()
+    assert same > 0.995, f"C3 crop radiance identical to the reference's for {same:.4f} of samples"
+    obj, tex, mat = synthetic_tables(int(g["n"]))
+    osc = build_table_scene(orc.Scene(orc.MATH_PORTABLE), tex, mat, obj, [[0.0, len(mat) - 1]], None, None, assets["sky"], int(g["build_key"]))
+    ref = osc.render(cam, W, H, S, B, seed, rect=rect, threads=16, want=("radiance", "rgba", "rng_draws"))
+    assert_bits(got["radiance"], ref["radiance"], "C3 crop radiance vs the oracle")
+    assert_bits(got["rng_draws"], ref["rng_draws"], "C3 crop RNG draws vs the oracle")
+    assert_bits(frame[y0:y1, x0:x1], ref["rgba"], "C3 crop colour vs the oracle")
+
+
+def test_c3_full_frame_properties(rt, golden, c3_scene):
+    """BASELINE's full size (100 000 primitives, 3840 x 2160, 256 spp, 8 bounces; 16 batches of 2^27 paths): the frame is
+    deterministic, a window renders the bytes of the frame, and the golden crop sits in it"""
+    g = golden("scene_c3")
+    scene, _ = c3_scene
+    cam = rt.camera_look(g["cam_pos"], g["cam_look"])
+    W, H, S, B = (int(v) for v in g["cfg"])
+    seed = int(g["seed"])
+    e = make_engine(rt, scene, W, H, S, B, cam)
+    a = e.render_frame(seed)
+    st = e.stats()
+    assert st["paths"] == W * H * S * S and st["rays"] > st["paths"]
+    assert e.cfg.max_batch_paths == 1 << 27 and W * H * S * S == 16 << 27
+    assert (a[..., 0] == 255).all()
+    x0, y0, x1, y1 = (int(v) for v in g["crop"])
+    assert_frame_close(a[y0:y1, x0:x1], g["crop_rgba"], "C3 full frame, crop region vs the reference")
+    e.set_window((1800, 1000, 2056, 1128))
+    c = e.render_frame(seed)
+    assert_bits(c[1000:1128, 1800:2056], a[1000:1128, 1800:2056], "C3 window vs full frame")
+    e.set_window(None)
+    b = e.render_frame(seed)
+    assert_bits(a, b, "two renders of the C3 frame")
