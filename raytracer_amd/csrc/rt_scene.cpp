@@ -8,7 +8,9 @@
 #include <algorithm>
 #include <cfloat>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <thread>
 
 using namespace rt;
 
@@ -82,32 +84,81 @@ Box3 box_of(const rt_scene& s, int idx) {
 
 // BVH_Node::BVH_Node (Object.cpp:181-225).  The reference copies the object vector in every node and sorts a
 // sub-range of the copy; children only touch disjoint sub-ranges, so sorting one shared vector in place is the same.
-int build_node(rt_scene& s, std::vector<int>& list, int start, int end) {
-    const int axis_draw = (int)(s.random01() * 3);
-    const int axis = axis_draw == 0 ? 0 : (axis_draw == 1 ? 1 : 2);
-    auto less = [&s, axis](int a, int b) { return box_of(s, a).mn[axis] < box_of(s, b).mn[axis]; };
-    const int span = end - start;
-    int left, right;
-    if (span == 1) left = right = list[start];
-    else if (span == 2) {
-        if (less(list[start], list[start + 1])) { left = list[start]; right = list[start + 1]; }
-        else { left = list[start + 1]; right = list[start]; }
-    } else {
-        std::sort(list.begin() + start, list.begin() + end, less);
-        const int mid = start + span / 2;
-        left = build_node(s, list, start, mid);
-        right = build_node(s, list, mid, end);
+//
+// The constructor draws one random number per node, parent before children, left subtree before right
+// (Object.cpp:191,215-216), so the counter a node draws with is its parent's plus one plus the nodes of everything built
+// before it — a function of the spans alone.  A span of 1 or 2 is one node; a span n >= 3 is one node plus the nodes of
+// its halves n/2 and n - n/2.  With the counters known up front, the two halves of a large span are built by different
+// threads: each draws the numbers the serial order would have drawn, sorts the same sub-range with the same comparator,
+// and writes its nodes into the slots the serial order (children before parent) would have used.
+struct NodeCount {
+    std::map<int, long long> memo;
+    long long operator()(int span) {
+        if (span <= 2) return 1;
+        auto it = memo.find(span);
+        if (it != memo.end()) return it->second;
+        const long long n = 1 + (*this)(span / 2) + (*this)(span - span / 2);
+        memo[span] = n;
+        return n;
     }
-    const Box3 bl = box_of(s, left), br = box_of(s, right);
-    Obj node;
-    node.kind = NODE;
-    node.left = left;
-    node.right = right;
-    // GetSurroundingBox (Object.cpp:156-166): fmin / fmax per component
-    node.box.mn = {std::fmin(bl.mn.x, br.mn.x), std::fmin(bl.mn.y, br.mn.y), std::fmin(bl.mn.z, br.mn.z)};
-    node.box.mx = {std::fmax(bl.mx.x, br.mx.x), std::fmax(bl.mx.y, br.mx.y), std::fmax(bl.mx.z, br.mx.z)};
-    s.objs.push_back(node);
-    return (int)s.objs.size() - 1;
+};
+struct TreeBuild {
+    rt_scene& s;
+    std::vector<int>& list;
+    const std::vector<Vec3>& mins;   // box minimum of every object index that occurs in the list (the sort key, Object.cpp:168-179)
+    NodeCount& count;                // filled for every span that can occur before the threads start: read-only afterwards
+    int build(int start, int end, uint32_t ctr, int slot) {
+        const float draw = (float)(int)rand31(s.rng_key, ctr) / 2147483648.0f;   // Random01, DataUtility.h:11
+        const int axis_draw = (int)(draw * 3);
+        const int axis = axis_draw == 0 ? 0 : (axis_draw == 1 ? 1 : 2);
+        const std::vector<Vec3>& m = mins;
+        auto less = [&m, axis](int a, int b) { return m[a][axis] < m[b][axis]; };
+        const int span = end - start;
+        int left, right;
+        int me;
+        if (span == 1) { left = right = list[start]; me = slot; }
+        else if (span == 2) {
+            if (less(list[start], list[start + 1])) { left = list[start]; right = list[start + 1]; }
+            else { left = list[start + 1]; right = list[start]; }
+            me = slot;
+        } else {
+            std::sort(list.begin() + start, list.begin() + end, less);
+            const int mid = start + span / 2;
+            const long long n_left = count.memo.count(mid - start) ? count.memo.at(mid - start) : 1, n_right = count.memo.count(end - mid) ? count.memo.at(end - mid) : 1;
+            if (span >= 8192) {   // large halves: the left one on another thread
+                int l = -1;
+                std::thread other([&] { l = build(start, mid, ctr + 1, slot); });
+                right = build(mid, end, ctr + 1 + (uint32_t)n_left, slot + (int)n_left);
+                other.join();
+                left = l;
+            } else {
+                left = build(start, mid, ctr + 1, slot);
+                right = build(mid, end, ctr + 1 + (uint32_t)n_left, slot + (int)n_left);
+            }
+            me = slot + (int)(n_left + n_right);
+        }
+        const Box3 bl = box_of(s, left), br = box_of(s, right);
+        Obj& node = s.objs[me];
+        node.kind = NODE;
+        node.left = left;
+        node.right = right;
+        // GetSurroundingBox (Object.cpp:156-166): fmin / fmax per component
+        node.box.mn = {std::fmin(bl.mn.x, br.mn.x), std::fmin(bl.mn.y, br.mn.y), std::fmin(bl.mn.z, br.mn.z)};
+        node.box.mx = {std::fmax(bl.mx.x, br.mx.x), std::fmax(bl.mx.y, br.mx.y), std::fmax(bl.mx.z, br.mx.z)};
+        return me;
+    }
+};
+int build_node(rt_scene& s, std::vector<int>& list, int start, int end) {
+    NodeCount count;
+    const long long n_nodes = count(end - start);
+    std::vector<Vec3> mins(s.objs.size(), Vec3{0, 0, 0});
+    for (int k = start; k < end; k++) mins[list[k]] = box_of(s, list[k]).mn;
+    const int slot = (int)s.objs.size();
+    s.objs.resize(s.objs.size() + (size_t)n_nodes);   // every node has its slot before any thread runs: the vector does not move
+    TreeBuild tb{s, list, mins, count};
+    const int root = tb.build(start, end, s.rng_ctr, slot);
+    s.rng_ctr += (uint32_t)n_nodes;
+    return root;
 }
 
 // PolygonMesh::PolygonMesh after parsing (Object.cpp:462-488): recentre, scale to `size`, one Triangle per 3 vertices

@@ -184,3 +184,17 @@ def test_alt_scene_is_the_first_six_rows_of_the_fog_fixture(golden, assets):
         assert_bits(x, y, "alternative scene BVH " + n)
     moved = rt.alt_scene(123, time=7.0)
     assert moved.dump_objects(7)[4][1] == np.float32(3 * np.sin(np.float64(np.float32(7.0) * np.float32(0.1))))
+
+
+def test_c3_tree_built_by_the_product(rt, golden, assets):
+    """the host builder on the 100 000-primitive scene: the reference's tree (digests of boxes, links, leaf order)"""
+    import time
+    g = golden("scene_c3")
+    obj, tex, mat = synthetic_tables(int(g["n"]))
+    t0 = time.perf_counter()
+    s = build_table_scene(rt.Scene(), tex, mat, obj, [[0.0, len(mat) - 1]], None, None, assets["sky"], int(g["build_key"]))
+    dt = time.perf_counter() - t0
+    for name, got in zip(("boxes", "left", "right", "leaf_ids"), s.dump_top()):
+        assert_bits(got[::1000], g[f"top_{name}_rows"], f"C3 tree {name}, every 1000th row")
+        assert hashlib.sha256(np.ascontiguousarray(got).tobytes()).digest() == g[f"top_{name}_sha256"].tobytes(), f"C3 tree {name}"
+    print(f"C3 scene through the C ABI: {dt:.2f} s including {int(g['n'])} object and material calls from Python")

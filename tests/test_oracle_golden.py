@@ -274,3 +274,29 @@ def test_portable_logf_is_the_rounded_double_log(orc):
     for x in xs:
         assert L.orc_pm_logf(float(x)) == np.float32(math.log(float(x)))
     assert L.orc_pm_logf(0.0) == -np.inf
+
+
+def test_c3_scene_at_full_size(orc, golden, assets):
+    """the 100 000-primitive scene: the oracle's tree is the reference's, and so are sample (0,0) of the 480 x 270 map
+    and an 8 x 8 corner of the 256 spp crop (ids, distances, draw counts; colour through libm like the reference)"""
+    g = golden("scene_c3")
+    obj, tex, mat = synthetic_tables(int(g["n"]))
+    s = build_table_scene(orc.Scene(orc.MATH_LIBM), tex, mat, obj, [[0.0, len(mat) - 1]], None, None, assets["sky"], int(g["build_key"]))
+    for name, got in zip(("boxes", "left", "right", "leaf_ids"), s.dump_top()):
+        assert_bits(got[::1000], g[f"top_{name}_rows"], f"C3 tree {name}, every 1000th row")
+        assert hashlib.sha256(np.ascontiguousarray(got).tobytes()).digest() == g[f"top_{name}_sha256"].tobytes(), f"C3 tree {name}"
+    cam = orc.camera(g["cam_pos"], g["cam_look"])
+    Wm, Hm, Sm, Bm = (int(v) for v in g["map_cfg"])
+    out = s.render(cam, Wm, Hm, Sm, Bm, int(g["seed"]), threads=8, want=("primary_id", "primary_t"))
+    assert_bits(out["primary_id"].reshape(Hm, Wm), g["map_primary_id"], "C3 map ids")
+    assert_bits(out["primary_t"].reshape(Hm, Wm), g["map_primary_t"], "C3 map distances")
+    W, H, S, B = (int(v) for v in g["cfg"])
+    x0, y0, x1, y1 = (int(v) for v in g["crop"])
+    out = s.render(cam, W, H, S, B, int(g["seed"]), rect=(x0, y0, x0 + 8, y0 + 8), threads=8, want=("primary_id", "primary_t", "rng_draws", "rgba", "radiance"))
+    sel = (np.arange(8)[:, None] * (x1 - x0) + np.arange(8)[None, :]).reshape(-1)
+    assert_bits(out["primary_id"], g["crop_primary_id"][sel], "C3 crop ids")
+    assert_bits(out["primary_t"], g["crop_primary_t"][sel], "C3 crop distances")
+    assert_bits(out["rng_draws"].astype(np.uint16), g["crop_rng_draws"][sel], "C3 crop draws")
+    assert_bits(out["rgba"], g["crop_rgba"][:8, :8], "C3 crop colour")
+    sub = (np.arange(8)[:, None] * 16 + np.arange(8)[None, :]).reshape(-1)     # the stored radiance covers 16 x 16 pixels
+    assert_bits(out["radiance"], g["crop_radiance"][sub], "C3 crop radiance")
