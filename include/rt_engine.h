@@ -47,8 +47,12 @@ typedef struct rt_config {
     int32_t device;                  /* HIP device ordinal                                           */
     int32_t max_batch_paths;         /* ray-queue capacity in paths (pixel samples) per batch; 0 = default */
     int32_t tile_w, tile_h;          /* image-space tile used to split a frame across GPUs; 0 = 64      */
-    int32_t flags;                   /* reserved, 0 */
+    int32_t flags;                   /* RT_FLAG_* bits, 0 by default */
 } rt_config;
+/* BVH_Node::Intersect (Object.cpp:241-252) descends into every box the ray hits.  For scenes too large for on-chip
+ * memory the engine skips boxes that provably lie behind the closest hit found so far (same results, fewer box tests);
+ * this flag makes it visit them all, as the reference does — for comparisons. */
+#define RT_FLAG_NO_CULL 1
 void rt_config_defaults(rt_config* cfg);   /* the values of Constants.h:4-17 */
 
 /* ---------------------------------------------------------------------------------------------------------
@@ -177,7 +181,9 @@ int rt_engine_trace_static(rt_engine* e, int n, const float* origins3, const flo
 int rt_engine_ray_color(rt_engine* e, int n, const float* origins3, const float* dirs3, int bounces, const uint32_t* keys, float* rgb3);
 
 /* Counters of the last render (always kept: they are the queue counters of the passes): paths, rays (closest-hit queries), rays per bounce level [0..32). */
-typedef struct rt_stats { uint64_t paths, rays; uint64_t rays_at_depth[33]; } rt_stats;
+/* box_tests: slab tests (BoundingBox::DoesRayHit, DataUtility.cpp:35-82) the engine executed — with distance culling fewer
+ * than the reference algorithm performs for the same rays. */
+typedef struct rt_stats { uint64_t paths, rays; uint64_t rays_at_depth[33]; uint64_t box_tests; } rt_stats;
 int rt_engine_get_stats(rt_engine* e, rt_stats* out);
 /* Time of the dominant kernel over the last render, from HIP events recorded on the render stream around every
  * launch of it: out[0] = total ms, out[1] = launches.  Only when enabled with rt_engine_time_kernels(e, 1). */

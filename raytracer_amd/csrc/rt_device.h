@@ -152,6 +152,9 @@ struct Scene {
     int top_end, stale_entry, n_planes;
     int n_entries, n_tris, n_inst, fast_div_ok, idle_entry;
     int has_fog;   // some entry is a fog volume: traversal consumes random numbers (Object.cpp:579)
+    // distance culling (see "distance culling" below): scene-wide constants of the bound; cull_on = 0 switches it off
+    float cull_delta, cull_cabs, cull_2rmax;
+    int cull_on;
 };
 struct Ray { V3 o, d; };
 
@@ -391,6 +394,10 @@ struct Walker {
     uint32_t alpha_wh;
     f2 e01, e23, e45;        // dwords 0..5 of the entry
     uint32_t sk;             // dword 6: kind << 28 | payload; for an inner entry (kind 0) simply the skip index
+    float rho;               // dword 7 of an inner entry: its culling parameter (+inf: never culled)
+    // distance culling: per-ray constants (cull_w = +inf: this ray never culls) and the current threshold
+    // base + k * rho(entry); base = +inf until the ray has a hit
+    float cull_w, cull_kray, cull_c, cull_base, cull_k;
     uint32_t f0, f1, f2, cnt;   // leaves visited but not yet tested, oldest first, and their number (0..3)
     float reach;                // > 0: the ray reaches the triangle f0 at this distance and tri_surface has yet to run
     Rng rng;                    // the path's random stream: fog volumes draw from it during traversal
@@ -414,10 +421,12 @@ __device__ __forceinline__ void walker_load(const Store& st, Walker& w) {
     const f2* e = reinterpret_cast<const f2*>(st.ent) + 4 * w.i;
     w.e01 = e[0]; w.e23 = e[1]; w.e45 = e[2];
     w.sk = reinterpret_cast<const uint32_t*>(e)[6];
+    w.rho = reinterpret_cast<const float*>(e)[7];
 }
 __device__ __forceinline__ void walker_idle(const Scene& sc, Walker& w) {
     w.i = sc.idle_entry; w.sk = (uint32_t)rt::ENT_IDLE << rt::SK_SHIFT;
-    w.e01 = f2{0, 0}; w.e23 = f2{0, 0}; w.e45 = f2{0, 0};
+    w.e01 = f2{0, 0}; w.e23 = f2{0, 0}; w.e45 = f2{0, 0}; w.rho = INFINITY;
+    w.cull_w = INFINITY; w.cull_kray = INFINITY; w.cull_c = INFINITY; w.cull_base = INFINITY; w.cull_k = 0.0f;
     w.p0 = f2{0, 0}; w.p1 = f2{0, 1}; w.p2 = f2{1, 1}; w.p3 = f2{1, 1}; w.p4 = f2{1, 0}; w.usable = true;
     w.s0 = w.p0; w.s1 = w.p1; w.s2 = w.p2; w.s3 = w.p3; w.s4 = w.p4; w.s_usable = true;
     w.resume = 0; w.inst = -1; w.stale = -1; w.alpha_off = -1; w.alpha_wh = 0;
@@ -425,9 +434,63 @@ __device__ __forceinline__ void walker_idle(const Scene& sc, Walker& w) {
     w.rng.key = 0; w.rng.ctr = 0;
     w.c.dist = FLT_MAX; w.c.best = -1; w.c.u = 0; w.c.v = 0; w.c.hit = false;
 }
+// ---------------------------------------------------------------------------------------------------- distance culling
+// BVH_Node::Intersect (Object.cpp:241-252) descends into every box the ray hits, also when the box lies wholly behind the
+// closest hit found so far.  Nothing in such a box can win: a leaf replaces the closest hit only with a strictly smaller
+// distance (Object.cpp:248).  The traversal of large scenes (entries in memory) therefore treats a box as missed when
+// its entry distance is PROVABLY beyond the current closest distance D — provably in the reference's own arithmetic,
+// because what must not be lost is a leaf whose COMPUTED distance is below D, whatever rounding did to it.
+//
+// Which boxes: inner entries of the top level whose subtree holds only spheres with a positive radius and cubes with
+// min <= max (the host marks every other inner entry with rho = +inf: below it may be a mesh instance — a triangle
+// nearly edge-on to the ray can get any distance at all —, a fog volume, which draws random numbers, or an inverted
+// box).  Which rays: those admitted to the reciprocal path whose direction has |d.d - 1| <= 2^-10.  A ray without a
+// hit culls nothing, so the leaf whose rejected HitInfo.distance survives (the first one tested) is never skipped.
+//
+// The bound.  Every inner box is the fmin/fmax union of its children's boxes (Object.cpp:156-166) and a leaf's box is
+// computed from the leaf in float, so with round-to-nearest being monotone, the entry distance the reference's slab
+// test computes for a box is <= the one it computes for any box below it, down to the float box B of a leaf.
+//   * Cube leaf: its Intersect IS that slab computation on B, so its distance is >= the entry of every box above.
+//   * Sphere leaf (c, r), accepted with distance t_c < D: with P, L as the reference computes them (Object.cpp:11-16)
+//     but exact, and E the rounding error of its discriminant, the point o + tau d at tau = P - sqrt(disc_c) lies
+//     exactly on the sphere of radius sqrt(r^2 + E + eta tau^2) about c, where |d|^2 = 1 + eta: for a far, small sphere
+//     the unit-length assumption of the formula is worth more than all rounding.  That point is inside B widened per
+//     axis by  g = (|E| + |eta| tau^2) / (2 r) + rounding of B and of L,  so  tau >= entry(B) - g / min|d_i|,  and
+//     t_c >= tau - 2^-21 (D + 2r).  With |E| <= 11 * 2^-24 (D + 2r)^2:
+//         t_c >= entry(box above) (1 - 2^-21) - W [delta + 2^-23 (D + 2 r_max) + rho eta' (D + 2 r_max)^2] - 2^-21 (D + 2 r_max)
+//     W = max |1/d_i| (1 + 2^-20), eta' = |fl(d.d) - 1| + 2^-20, rho = max 1 / (2r) below the box,
+//     delta = 2^-23 max(|c_i| + r).
+// The one-multiplication entry distance the box step decides on is within 1.5 * 2^-23 of the reference's, hence a box
+// is skipped when that distance exceeds
+//         D (1 + 2^-16 + 2^-23 W) + 2^-16 r_max + W (delta + 2^-22 r_max)  +  W eta' (D + 2 r_max)^2 * rho
+//         \_______________________________ cull_base _________________/     \________ cull_k ________/
+// (margins 2^-16 where 2^-19 would do).  cull_base and cull_k change only when the closest hit does.
+template <bool CULL>
+__device__ __forceinline__ void cull_start(const Scene& sc, Walker& w, const Ray& ray) {
+    w.cull_base = INFINITY; w.cull_k = 0.0f;
+    w.cull_w = INFINITY; w.cull_kray = INFINITY; w.cull_c = INFINITY;
+    if (!CULL) return;
+    const float eta = fabsf(dot(ray.d, ray.d) - 1.0f) + 9.5367431640625e-07f;
+    if (sc.cull_on && w.usable && eta <= 9.765625e-04f) {
+        const float W = fmaxf(fabsf(w.p1.y), fmaxf(fabsf(w.p2.x), fabsf(w.p2.y))) * 1.000001f;
+        w.cull_w = W;
+        w.cull_kray = W * eta * 1.000001f;
+        w.cull_c = sc.cull_cabs + W * sc.cull_delta * 1.000001f;
+    }
+}
+template <bool CULL>
+__device__ __forceinline__ void cull_update(const Scene& sc, Walker& w, float D) {
+    if (!CULL) return;
+    w.cull_base = D * (1.0000153f + w.cull_w * 1.1920928955078125e-07f) + w.cull_c;
+    const float dd = D + sc.cull_2rmax;
+    w.cull_k = w.cull_kray * dd * dd;
+}
+
+template <bool CULL = false>
 __device__ __forceinline__ void walker_start(const Scene& sc, const Store& st, Walker& w, const Ray ray, const Rng rng) {
     w.rng = rng;
     walker_set_ray(w, ray, sc.fast_div_ok != 0);
+    cull_start<CULL>(sc, w, ray);
     w.i = 0; w.resume = 0; w.inst = -1; w.stale = sc.stale_entry; w.alpha_off = -1; w.alpha_wh = 0;
     w.f0 = 0; w.f1 = 0; w.f2 = 0; w.cnt = 0; w.reach = 0.0f;
     w.c.dist = FLT_MAX; w.c.best = -1; w.c.u = 0; w.c.v = 0; w.c.hit = false;
@@ -485,11 +548,12 @@ struct Prof { unsigned long long box = 0, prim = 0, special = 0, refill = 0; uns
 #define RT_BOX_COUNT_OPERANDS
 #endif
 template <bool LDS>
-__device__ __forceinline__ void box_steps(const Store& st, Walker& w, int quorum, Prof& prof) {
+__device__ __forceinline__ void box_steps(const Store& st, Walker& w, int quorum, Prof& prof, uint32_t& n_box) {
     const unsigned long long px = __ballot(w.p3.x >= 0), py = __ballot(w.p3.y >= 0), pz = __ballot(w.p4.x >= 0);
     const unsigned long long usable = __ballot(w.usable);
-    unsigned long long m, m2, m3, mall, saved;
+    unsigned long long m, m2, m3, m4, mall, saved;
     int n_inner;
+    uint32_t nb = 0;   // slab tests executed by this call (lanes x iterations), summed in a scalar register
     RT_PROF(int box_iters = 0; int box_lanes = 0;)
     if (LDS) {
         const uint32_t base = (uint32_t)(uintptr_t)st.ent;   // LDS addresses are 32-bit offsets
@@ -584,12 +648,13 @@ __device__ __forceinline__ void box_steps(const Store& st, Walker& w, int quorum
                  "s_waitcnt lgkmcnt(0)\n\t"
                  "s_mov_b64 exec, %[saved]\n\t"
                  "s_bcnt1_i32_b64 %[cntS], %[m]\n\t"
+                 "s_add_u32 %[nbox], %[nbox], %[cntS]\n\t"
                  "s_cmp_ge_u32 %[cntS], %[quorum]\n\t"
                  "s_cbranch_scc1 1b\n\t"
                  "2:\n\t"
                  : [e01] "+v"(w.e01), [e23] "+v"(w.e23), [e45] "+v"(w.e45), [sk] "+v"(w.sk), [i] "+v"(w.i), [f0] "+v"(w.f0),
                    [f1] "+v"(w.f1), [f2] "+v"(w.f2), [cnt] "+v"(w.cnt), [m] "=&s"(m), [m2] "=&s"(m2), [m3] "=&s"(m3),
-                   [mall] "=&s"(mall), [saved] "=&s"(saved), [cntS] "=&s"(n_inner) RT_BOX_COUNT_OPERANDS
+                   [mall] "=&s"(mall), [saved] "=&s"(saved), [cntS] "=&s"(n_inner), [nbox] "+s"(nb) RT_BOX_COUNT_OPERANDS
                  : [p0] "v"(w.p0), [p1] "v"(w.p1), [p2] "v"(w.p2), [p3] "v"(w.p3), [p4] "v"(w.p4), [px] "s"(px), [py] "s"(py),
                    [pz] "s"(pz), [base] "s"(base), [usable] "s"(usable), [quorum] "s"(quorum)
                  : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18",
@@ -625,8 +690,10 @@ __device__ __forceinline__ void box_steps(const Store& st, Walker& w, int quorum
                  "v_cndmask_b32_e64 v7, v6, v7, %[pz]\n\t"
                  "v_max3_f32 v8, v8, v2, v4\n\t"
                  "v_min3_f32 v3, v3, v5, v7\n\t"
+                 "v_fma_f32 v5, %[ck], %[rho], %[cbase]\n\t"
                  "v_cmp_le_f32_e32 vcc, v8, v3\n\t"
                  "v_cmp_nlt_f32_e64 %[m3], v3, 0\n\t"
+                 "v_cmp_ngt_f32_e64 %[m4], v8, v5\n\t"
                  "v_sub_f32_e32 v9, v3, v8\n\t"
                  "v_max_f32_e64 v2, |v8|, |v3|\n\t"
                  "s_and_b64 vcc, vcc, %[m3]\n\t"
@@ -663,6 +730,7 @@ __device__ __forceinline__ void box_steps(const Store& st, Walker& w, int quorum
                  "v_add_u32_e32 v4, 1, %[i]\n\t"
                  "s_and_b64 vcc, vcc, %[m3]\n\t"
                  "5:\n\t"
+                 "s_and_b64 vcc, vcc, %[m4]\n\t"
                  "s_nop 0\n\t"
                  "v_cndmask_b32_e32 %[i], %[sk], v4, vcc\n\t"
                  "3:\n\t"
@@ -687,19 +755,22 @@ __device__ __forceinline__ void box_steps(const Store& st, Walker& w, int quorum
                  "v_pk_mov_b32 %[e23], v[12:13], v[12:13] op_sel:[0,1]\n\t"
                  "v_pk_mov_b32 %[e45], v[14:15], v[14:15] op_sel:[0,1]\n\t"
                  "v_mov_b32_e32 %[sk], v16\n\t"
+                 "v_mov_b32_e32 %[rho], v17\n\t"
                  "s_mov_b64 exec, %[saved]\n\t"
                  "s_bcnt1_i32_b64 %[cntS], %[m]\n\t"
+                 "s_add_u32 %[nbox], %[nbox], %[cntS]\n\t"
                  "s_cmp_ge_u32 %[cntS], %[quorum]\n\t"
                  "s_cbranch_scc1 1b\n\t"
                  "2:\n\t"
                  : [e01] "+v"(w.e01), [e23] "+v"(w.e23), [e45] "+v"(w.e45), [sk] "+v"(w.sk), [i] "+v"(w.i), [f0] "+v"(w.f0),
                    [f1] "+v"(w.f1), [f2] "+v"(w.f2), [cnt] "+v"(w.cnt), [m] "=&s"(m), [m2] "=&s"(m2), [m3] "=&s"(m3),
-                   [mall] "=&s"(mall), [saved] "=&s"(saved), [cntS] "=&s"(n_inner) RT_BOX_COUNT_OPERANDS
+                   [mall] "=&s"(mall), [saved] "=&s"(saved), [cntS] "=&s"(n_inner), [m4] "=&s"(m4), [rho] "+v"(w.rho), [nbox] "+s"(nb) RT_BOX_COUNT_OPERANDS
                  : [p0] "v"(w.p0), [p1] "v"(w.p1), [p2] "v"(w.p2), [p3] "v"(w.p3), [p4] "v"(w.p4), [px] "s"(px), [py] "s"(py),
-                   [pz] "s"(pz), [base] "s"(base), [usable] "s"(usable), [quorum] "s"(quorum)
+                   [pz] "s"(pz), [base] "s"(base), [usable] "s"(usable), [quorum] "s"(quorum), [ck] "v"(w.cull_k), [cbase] "v"(w.cull_base)
                  : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18",
                    "v19", "v20", "v21", "vcc", "scc", "memory");
     }
+    n_box += nb;
     RT_PROF(prof.box_iters += box_iters; prof.box_lanes += box_lanes;)
 }
 
@@ -707,9 +778,11 @@ __device__ __forceinline__ void box_steps(const Store& st, Walker& w, int quorum
 // BVH_Node::Intersect (Object.cpp:245-251) and World::GetRayColor (World.cpp:110-118).  A triangle the ray reaches stays
 // at the head of the FIFO with its distance in `reach` when the rest of its test can matter — the distance would win, or
 // the leaf is the one whose assignment of HitInfo.distance survives a rejection — and is finished by tri_finish_step.
-__device__ __forceinline__ void closest_update(Walker& w, int e, bool ok, bool wrote, float t, float u, float v) {
+template <bool CULL>
+__device__ __forceinline__ void closest_update(const Scene& sc, Walker& w, int e, bool ok, bool wrote, float t, float u, float v) {
     // selects rather than branches around the updates: the record stays in registers
     const bool better = ok && (!w.c.hit || t < w.c.dist);
+    if (CULL && better) cull_update<CULL>(sc, w, t);
     const bool stale = !ok && wrote && e == w.stale;
     w.c.dist = (better || stale) ? t : w.c.dist;
     w.c.best = better ? e : w.c.best;
@@ -717,7 +790,7 @@ __device__ __forceinline__ void closest_update(Walker& w, int e, bool ok, bool w
     w.c.v = better ? v : w.c.v;
     w.c.hit = w.c.hit || better;
 }
-template <bool FOG>
+template <bool FOG, bool CULL>
 __device__ __forceinline__ void prim_step(const Scene& sc, const Store& st, Walker& w) {
     const int e = (int)w.f0;
     const f2* E = reinterpret_cast<const f2*>(st.ent) + 4 * (size_t)e;
@@ -737,9 +810,10 @@ __device__ __forceinline__ void prim_step(const Scene& sc, const Store& st, Walk
     }
     w.reach = wait ? t : 0.0f;
     w.f0 = wait ? w.f0 : w.f1; w.f1 = wait ? w.f1 : w.f2; w.cnt -= wait ? 0u : 1u;
-    closest_update(w, e, ok, wrote, t, 0.0f, 0.0f);
+    closest_update<CULL>(sc, w, e, ok, wrote, t, 0.0f, 0.0f);
 }
 // The second part of Triangle::Intersect for a lane whose head-of-FIFO triangle is waiting for it.
+template <bool CULL>
 __device__ __forceinline__ void tri_finish_step(const Scene& sc, const Store& st, Walker& w) {
     const int e = (int)w.f0;
     w.f0 = w.f1; w.f1 = w.f2; w.cnt--;
@@ -748,7 +822,7 @@ __device__ __forceinline__ void tri_finish_step(const Scene& sc, const Store& st
     bool wrote = false;
     const bool ok = tri_surface(sc, st.tris, sk_payload(sk), w.alpha_off, w.alpha_wh, walker_ray(w), w.reach, t, u, v, wrote);
     w.reach = 0.0f;
-    closest_update(w, e, ok, wrote, t, u, v);
+    closest_update<CULL>(sc, w, e, ok, wrote, t, u, v);
 }
 // Entries that change the lane's state beyond its position; they wait until every noted leaf has been tested.  Returns
 // true when the ray has finished (closest hit known, plane list merged); the lane is idle from then on.
@@ -792,7 +866,7 @@ __device__ __forceinline__ bool walker_special(const Scene& sc, const Store& st,
 // One round for a wave: the traversal loop; then primitive tests, repeated while at least `prim_quorum` lanes have a
 // noted leaf; then the state-changing entries of lanes that have none left.  Returns true in lanes whose ray finished.
 template <bool LDS, bool FOG>
-__device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Walker& w, int quorum, int prim_quorum, int finish_quorum, Prof& prof) {
+__device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Walker& w, int quorum, int prim_quorum, int finish_quorum, Prof& prof, uint32_t& n_box) {
     RT_PROF(unsigned long long t0 = __builtin_readcyclecounter(); prof.rounds++;)
     // with few rays in the wave (the last rays of a pass) a fixed quorum is never met and every round would advance each
     // ray by a single step: ask for half of the lanes that hold a ray instead
@@ -800,14 +874,15 @@ __device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Wal
     quorum = max(1, min(quorum, (busy + 1) >> 1));
     prim_quorum = max(1, min(prim_quorum, (busy + 1) >> 1));
     finish_quorum = max(1, min(finish_quorum, (busy + 1) >> 1));
-    box_steps<LDS>(st, w, quorum, prof);
+    constexpr bool CULL = !LDS && !FOG;   // see "distance culling": large scenes, and never when traversal draws random numbers
+    box_steps<LDS>(st, w, quorum, prof, n_box);
     RT_PROF(unsigned long long t1 = __builtin_readcyclecounter(); prof.box += t1 - t0;)
     for (;;) {
         const bool has = w.cnt != 0 && w.reach == 0.0f;
         const int n = __popcll(__ballot(has));
         if (n == 0) break;
         RT_PROF(prof.prims++; prof.prim_lanes += n;)
-        if (has) prim_step<FOG>(sc, st, w);
+        if (has) prim_step<FOG, CULL>(sc, st, w);
         if (n < prim_quorum) break;
     }
     // triangles waiting for the second part of their test: run it once enough lanes have one (a waiting lane goes on
@@ -817,7 +892,7 @@ __device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Wal
         const int n = __popcll(__ballot(waiting));
         if (n >= finish_quorum) {
             RT_PROF(prof.finishes++; prof.finish_lanes += n;)
-            if (waiting) tri_finish_step(sc, st, w);
+            if (waiting) tri_finish_step<CULL>(sc, st, w);
         }
     }
     RT_PROF(unsigned long long t2 = __builtin_readcyclecounter(); prof.prim += t2 - t1;)
@@ -826,14 +901,17 @@ __device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Wal
                                         (kind == rt::ENT_INNER && !w.usable));
     bool done = false;
     RT_PROF(if (__any(special)) prof.specials++;)
+    n_box += (uint32_t)__popcll(__ballot(special && (kind == rt::ENT_INNER_INV || kind == rt::ENT_INNER)));   // boxes tested as written
     if (special) done = walker_special(sc, st, w);
     RT_PROF(prof.special += __builtin_readcyclecounter() - t2;)
     return done;
 }
 // Run the lanes of a wave until all of them have finished.
+template <bool FOG>
 __device__ __forceinline__ void walk_wave_to_end(const Scene& sc, const Store& st, Walker& w) {
     Prof prof;
-    while (__any(sk_kind(w.sk) != rt::ENT_IDLE)) walk_round<false, true>(sc, st, w, 24, 32, 16, prof);
+    uint32_t n_box = 0;
+    while (__any(sk_kind(w.sk) != rt::ENT_IDLE)) walk_round<false, FOG>(sc, st, w, 24, 32, 16, prof, n_box);
 }
 __device__ __forceinline__ bool walker_is_idle(const Walker& w) { return sk_kind(w.sk) == rt::ENT_IDLE; }
 

@@ -51,6 +51,7 @@ constexpr int MAX_STAGED_BYTES = 80 * 1024;   // largest scene copy a block keep
 constexpr int NCUR = 32, CUR_STRIDE = 1024;
 constexpr int STRIPE = 512;          // positions per stripe; range r of a queue is every NCUR-th stripe, starting with stripe r
 constexpr int COUNT_WORDS = CUR_STRIDE * (1 + NCUR);   // per batch: ray counts per pass, then NCUR rows of counters
+constexpr int BOX_COUNT_AT = 512;   // words BOX_COUNT_AT + 2k, + 2k + 1 of a batch's first row: box tests executed by pass k (64 bits)
 constexpr int STILE = 1024;         // shade: queue positions a block handles per round (survivors staged in 32 KiB of LDS)
 // intersect scheduling knobs (defaults in rt_engine_create; RT_REFILL_AT / RT_QUORUM / RT_CHUNK override them for tuning)
 struct Tune {
@@ -242,6 +243,8 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
     uint32_t chunk = (n_in / (waves * (uint32_t)tune.guide)) & ~7u;
     chunk = chunk < (uint32_t)tune.min_chunk ? (uint32_t)tune.min_chunk : (chunk > (uint32_t)tune.chunk ? (uint32_t)tune.chunk : chunk);
     bool drained = false;   // wave-uniform: every queue position has been handed out
+    uint32_t n_box = 0;     // wave-uniform: slab tests this wave executed (lanes x iterations)
+    constexpr bool CULL = !STAGED && !FOG;
     Prof prof;
     RT_PROF(const unsigned long long t_start = __builtin_readcyclecounter(); unsigned n_refills = 0;)
     for (;;) {
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
                     Ray ray; Rng rng; uint32_t slot, depth;
                     if (fetch_ray<FIRST>(cam, g, bt, q, qin, dbg, idx, ray, rng, slot, depth, FOG)) {
                         my_idx = idx;
-                        walker_start(sc, st, w, ray, rng);
+                        walker_start<CULL>(sc, st, w, ray, rng);
                     }
                 }
                 const uint32_t took = (uint32_t)__popcll(idle);
@@ -301,11 +304,12 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
             if (drained) break;
             continue;
         }
-        if (walk_round<STAGED, FOG>(sc, st, w, tune.quorum, tune.prim_quorum, tune.finish_quorum, prof)) {
+        if (walk_round<STAGED, FOG>(sc, st, w, tune.quorum, tune.prim_quorum, tune.finish_quorum, prof, n_box)) {
             q.hit[my_idx] = make_float4(w.c.dist, __int_as_float(w.c.best), w.c.u, w.c.v);
             if (FOG) q.hit_ctr[my_idx] = w.rng.ctr;
         }
     }
+    if (lane == 0 && n_box) atomicAdd(reinterpret_cast<unsigned long long*>(q.counts + BOX_COUNT_AT) + pass, (unsigned long long)n_box);
 #ifdef RT_PROFILE
     if (dbg.prof && lane == 0 && prof.rounds) {   // per pass: 12 counters summed over the waves that had work
         unsigned long long* p = dbg.prof + 16 * (pass < 15 ? pass : 15);
@@ -471,7 +475,9 @@ __global__ __launch_bounds__(256) void assemble_kernel(Cfg g, Batch bt, const ui
     out[(size_t)py * g.W + px] = gathered[i];
 }
 
-// closest-hit queries for arbitrary rays (same walker, scene read from global memory)
+// closest-hit queries for arbitrary rays (same walker, scene read from global memory; like the render kernels, compiled
+// with and without fog support, and culling by distance without it)
+template <bool FOG>
 __global__ __launch_bounds__(256) void trace_kernel(Scene sc, int n, const float* o3, const float* d3, int32_t* hit_id, float* rec9) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     Store st;
@@ -484,9 +490,9 @@ __global__ __launch_bounds__(256) void trace_kernel(Scene sc, int n, const float
         r.o = mk(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]);
         r.d = mk(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]);
         Rng rng; rng.key = (uint32_t)i; rng.ctr = 0;   // fog volumes draw random numbers: one stream per ray
-        walker_start(sc, st, w, r, rng);
+        walker_start<!FOG>(sc, st, w, r, rng);
     }
-    walk_wave_to_end(sc, st, w);
+    walk_wave_to_end<FOG>(sc, st, w);
     if (i >= n) return;
     const Closest& c = w.c;
     float* q = rec9 + 9 * (size_t)i;
@@ -852,7 +858,7 @@ static int rt_engine_set_scene_impl(rt_engine* e, const rt_scene* s) {
         switch (kind) {
         case rt::ENT_INNER:
             a = {lo.x, hi.x, lo.y, hi.y};
-            if (lo.x <= hi.x && lo.y <= hi.y && lo.z <= hi.z) b = {lo.z, hi.z, lo.w, 0};
+            if (lo.x <= hi.x && lo.y <= hi.y && lo.z <= hi.z) b = {lo.z, hi.z, lo.w, f->ent_rho[i]};
             else b = {lo.z, hi.z, tag(rt::ENT_INNER_INV, 0), lo.w};
             break;
         case rt::ENT_SPHERE: a = lo; b.z = tag(kind, rt::bits_i(hi.x)); break;
@@ -937,6 +943,8 @@ static int rt_engine_set_scene_impl(rt_engine* e, const rt_scene* s) {
     sc.n_entries = (int)f->ent_lo.size(); sc.n_tris = (int)f->tris.size() / rt::RT_TRI_F4; sc.n_inst = (int)f->inst.size() / rt::RT_INST_F4; sc.fast_div_ok = f->fast_div_ok ? 1 : 0;
     sc.idle_entry = f->idle_entry;
     sc.has_fog = has_fog ? 1 : 0;
+    sc.cull_delta = f->cull_delta; sc.cull_cabs = f->cull_cabs; sc.cull_2rmax = f->cull_2rmax;
+    sc.cull_on = (e->cfg.flags & RT_FLAG_NO_CULL) ? 0 : 1;
     e->sc = sc;
     // stage the whole scene in LDS when two 512-thread blocks per CU can each hold it (160 KiB per CU)
     const size_t need = (inter.size() + f->tris.size() + f->inst.size() + f->planes.size()) * 16;
@@ -1122,7 +1130,8 @@ int rt_engine_trace(rt_engine* e, int n, const float* o3, const float* d3, int32
         if (hipMalloc((void**)&d_hit, (size_t)n * 4) != hipSuccess || hipMalloc((void**)&d_rec, (size_t)n * 36) != hipSuccess)
             rc = fail(RT_E_NOMEM, "device allocation failed");
         else {
-            hipLaunchKernelGGL(trace_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->sc, n, d_o, d_d, d_hit, d_rec);
+            if (e->sc.has_fog) hipLaunchKernelGGL(trace_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->sc, n, d_o, d_d, d_hit, d_rec);
+            else hipLaunchKernelGGL(trace_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->sc, n, d_o, d_d, d_hit, d_rec);
             hipError_t he = hipStreamSynchronize(e->stream);
             if (he != hipSuccess) rc = fail(RT_E_DEVICE, hipGetErrorString(he));
             else {
@@ -1154,7 +1163,8 @@ int rt_engine_trace_static(rt_engine* e, int n, const float* o3, const float* d3
     float* d_rec = reinterpret_cast<float*>(base + (size_t)RT_TRACE_STATIC_MAX_RAYS * 28);
     HIP_TRY(hipMemcpyAsync(d_o, o3, (size_t)n * 12, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(d_d, d3, (size_t)n * 12, hipMemcpyHostToDevice, e->stream));
-    hipLaunchKernelGGL(trace_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->sc, n, d_o, d_d, d_hit, d_rec);
+    if (e->sc.has_fog) hipLaunchKernelGGL(trace_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->sc, n, d_o, d_d, d_hit, d_rec);
+    else hipLaunchKernelGGL(trace_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->sc, n, d_o, d_d, d_hit, d_rec);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(hit_id, d_hit, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipMemcpyAsync(rec9, d_rec, (size_t)n * 36, hipMemcpyDeviceToHost, e->stream));
@@ -1213,8 +1223,13 @@ static int rt_engine_get_stats_impl(rt_engine* e, rt_stats* out) {
     if (nb <= 0) return RT_OK;
     e->h_counts.resize((size_t)nb * per_batch);
     HIP_TRY(hipMemcpy(e->h_counts.data(), e->d_counts_all, sizeof(uint32_t) * (size_t)nb * per_batch, hipMemcpyDeviceToHost));
-    for (int b = 0; b < nb; b++)
+    for (int b = 0; b < nb; b++) {
         for (int k = 1; k < nc - 1 && k < 33; k++) out->rays_at_depth[k] += e->h_counts[(size_t)b * per_batch + k];
+        for (int k = 0; k < nc - 1 && k < 33; k++) {
+            const uint32_t* w2 = &e->h_counts[(size_t)b * per_batch + BOX_COUNT_AT + 2 * k];
+            out->box_tests += (uint64_t)w2[0] | ((uint64_t)w2[1] << 32);
+        }
+    }
 #ifdef RT_PROFILE
     if (e->dbg.prof) {
         unsigned long long h[16 * 16];

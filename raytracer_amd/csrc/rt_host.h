@@ -69,6 +69,12 @@ struct rt_scene_flat {
     rt::ImageRec sky{0, 0, 0, 0};
     int32_t top_end = 0, stale_entry = -1, idle_entry = 0;
     bool fast_div_ok = false;                // every box coordinate is 0 or has magnitude in [2^-50, 2^40] (see rt_device.h, div_by)
+    // Distance culling (rt_device.h, "distance culling"): per entry, for inner entries of the top level, the largest
+    // 1 / (2 radius) over the spheres below it (0 when only cubes are below), or +inf when something below may not be
+    // culled (a mesh instance, a fog volume, a sphere with a negative radius, a cube with min > max); and the
+    // scene-wide constants of the bound.
+    std::vector<float> ent_rho;
+    float cull_delta = 0, cull_cabs = 0, cull_2rmax = 0;
 };
 
 const rt_scene_flat* rt_scene_get_flat(const struct rt_scene* s);

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cstring>
+#include <limits>
 #include <map>
 #include <memory>
 #include <thread>
@@ -338,6 +339,39 @@ void flatten(rt_scene& s) {
             const float a = std::fabs(v);
             if (!(v == 0.0f || (a >= 8.8817841970012523e-16f && a <= 1.099511627776e12f))) f.fast_div_ok = false;
         }
+    }
+    // Distance culling data (see rt_device.h).  Entries are in preorder and an inner entry's skip index is the end of its
+    // subtree, so walking the indices downwards meets both children of an entry before the entry itself.
+    {
+        const float INF = std::numeric_limits<float>::infinity();
+        const size_t n = f.ent_lo.size();
+        f.ent_rho.assign(n, INF);
+        float r_max = 0, c_max = 0;
+        for (int i = f.top_end - 1; i >= 0; i--) {
+            const int kind = bits_i(f.ent_hi[i].w);
+            if (kind == ENT_SPHERE) {
+                const float r = f.ent_lo[i].w;
+                const float cm = std::fmax(std::fabs(f.ent_lo[i].x), std::fmax(std::fabs(f.ent_lo[i].y), std::fabs(f.ent_lo[i].z)));
+                if (r > 0 && r <= FLT_MAX && cm <= FLT_MAX) {
+                    f.ent_rho[i] = (0.5f / r) * 1.000001f;
+                    r_max = std::fmax(r_max, r);
+                    c_max = std::fmax(c_max, cm + r);
+                }
+            } else if (kind == ENT_CUBE) {
+                const bool ordered = f.ent_lo[i].x <= f.ent_hi[i].x && f.ent_lo[i].y <= f.ent_hi[i].y && f.ent_lo[i].z <= f.ent_hi[i].z;
+                if (ordered) f.ent_rho[i] = 0.0f;
+            } else if (kind == ENT_INNER) {
+                const int skip = bits_i(f.ent_lo[i].w), c1 = i + 1;
+                const int c2 = bits_i(f.ent_hi[c1].w) == ENT_INNER ? bits_i(f.ent_lo[c1].w) : c1 + 1;
+                float rho = f.ent_rho[c1];
+                if (c2 < skip) rho = std::fmax(rho, f.ent_rho[c2]);      // a node over one object lists it once
+                const bool ordered = f.ent_lo[i].x <= f.ent_hi[i].x && f.ent_lo[i].y <= f.ent_hi[i].y && f.ent_lo[i].z <= f.ent_hi[i].z;
+                f.ent_rho[i] = ordered ? rho : INF;
+            }
+        }
+        f.cull_2rmax = 2.0f * r_max;
+        f.cull_cabs = r_max * 1.52587890625e-05f;                                    // 2^-16 r_max
+        f.cull_delta = (c_max + 2.0f * r_max) * 1.1920928955078125e-07f;             // 2^-23 (max |c| + r) + 2^-22 r_max
     }
     // texel pool: images, then the skybox; each padded by one zero row because uv == 1.0 indexes row h
     // (Object.cpp:546-547 wrap; World.cpp:174-183 has no clamp)

@@ -15,6 +15,7 @@ ASSET_DIR = os.path.join(os.path.dirname(HERE), "assets")
 MAT_NONE, MAT_DIFFUSE, MAT_METAL, MAT_ISOTROPIC, MAT_LIGHT = 0, 1, 2, 3, 4
 TEX_COLOR, TEX_CHECKER, TEX_IMAGE = 0, 1, 2
 TRACE_STATIC_MAX_RAYS = 32768   # RT_TRACE_STATIC_MAX_RAYS
+FLAG_NO_CULL = 1                # RT_FLAG_NO_CULL
 
 f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
@@ -37,7 +38,7 @@ class Config(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("paths", C.c_uint64), ("rays", C.c_uint64), ("rays_at_depth", C.c_uint64 * 33)]
+    _fields_ = [("paths", C.c_uint64), ("rays", C.c_uint64), ("rays_at_depth", C.c_uint64 * 33), ("box_tests", C.c_uint64)]
 
 
 # every symbol include/rt_engine.h declares: name -> (restype, argtypes)
@@ -409,7 +410,8 @@ class Engine:
     def stats(self):
         st = Stats()
         _check(self.L.rt_engine_get_stats(self.h, C.byref(st)))
-        return {"paths": int(st.paths), "rays": int(st.rays), "rays_at_depth": [int(v) for v in st.rays_at_depth]}
+        return {"paths": int(st.paths), "rays": int(st.rays), "rays_at_depth": [int(v) for v in st.rays_at_depth],
+                "box_tests": int(st.box_tests)}
 
     def time_kernels(self, enable=True):
         _check(self.L.rt_engine_time_kernels(self.h, int(enable)))

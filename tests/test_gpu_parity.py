@@ -526,6 +526,84 @@ def test_random_scenes_bit_exact(rt, orc, assets, seed):
     assert_bits(frame, ref["rgba"], f"random scene {seed}: frame")
 
 
+def _culling_stress_rays(obj, rng, n_targets):
+    """rays aimed at the silhouettes of spheres (where the computed distance is worst conditioned), from far away, a share
+    of them nearly parallel to a coordinate axis (where a box face is crossed slowly), some with directions that are not
+    of unit length (the reference's sphere formula assumes it), plus plain random rays"""
+    sph = obj[obj[:, 0] == 0]
+    pick = sph[rng.integers(0, len(sph), n_targets)]
+    c, r = pick[:, 1:4].astype(np.float64), np.abs(pick[:, 4:5].astype(np.float64))
+    dist = rng.uniform(5.0, 400.0, (n_targets, 1))
+    u = rng.normal(size=(n_targets, 3))
+    k = n_targets // 3
+    axis = rng.integers(0, 3, k)
+    u[:k] = rng.normal(size=(k, 3)) * np.exp(rng.uniform(np.log(1e-7), np.log(1e-2), (k, 1)))
+    u[np.arange(k), axis] = rng.choice([-1.0, 1.0], k)
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    o = c - u * dist
+    p = np.cross(u, rng.normal(size=(n_targets, 3)))
+    p /= np.linalg.norm(p, axis=1, keepdims=True)
+    eps = rng.choice([0.0, 1e-7, -1e-7, 1e-6, -1e-6, 1e-5, -1e-5, 1e-4, -1e-4, 1e-3, -1e-3, -0.5, -0.9], (n_targets, 1))
+    d = c + r * (1.0 + eps) * p - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d32 = d.astype(np.float32)
+    d32 /= np.sqrt((d32.astype(np.float64) ** 2).sum(axis=1, keepdims=True)).astype(np.float32)
+    scale = np.ones((n_targets, 1), np.float32)
+    scale[::7] = np.float32(1.0 + 3e-4)          # |d.d - 1| below the culling limit, far above rounding
+    scale[3::11] = np.float32(0.9)               # above it: such a ray culls nothing
+    d32 *= scale
+    ro = rng.uniform([-150, 0.5, -200], [150, 60, 150], (n_targets // 2, 3)).astype(np.float32)
+    rd = rng.normal(size=(n_targets // 2, 3)).astype(np.float32)
+    rd /= np.linalg.norm(rd, axis=1, keepdims=True).astype(np.float32)
+    return np.concatenate([o.astype(np.float32), ro]), np.concatenate([d32, rd])
+
+
+def test_distance_culling_changes_nothing(rt, orc, assets):
+    """Boxes behind the closest hit are skipped in scenes too large for on-chip memory.  The skipped boxes must be exactly
+    those that cannot matter: ids, distances and radiance with culling, without it (RT_FLAG_NO_CULL) and from the oracle,
+    which like the reference visits everything, are compared bit for bit on rays chosen to sit on the culling bound's
+    weak spots, in a scene with spheres from 1 mm to 30 m next to each other."""
+    rng = np.random.default_rng(77)
+    obj, tex, mat = synthetic_tables(3000)
+    extra = np.zeros((300, 10), np.float32)
+    extra[:, 0] = 0
+    extra[:, 1:4] = rng.uniform([-100, 1, -100], [100, 41, 100], (300, 3))
+    extra[:200, 4] = np.exp(rng.uniform(np.log(1e-3), np.log(5e-2), 200))
+    extra[200:250, 4] = rng.uniform(3.0, 30.0, 50)
+    extra[250:, 0] = 2
+    extra[250:, 4] = rng.uniform(0.05, 6.0, 50)
+    extra[:, 9] = rng.integers(0, 3000, 300)
+    obj = np.concatenate([obj, extra])
+    plane = [[0.0, len(mat) - 1]]
+    args = (tex, mat, obj, plane, None, None, assets["sky"], 4242)
+    scene = build_table_scene(rt.Scene(), *args)
+    osc = build_table_scene(orc.Scene(orc.MATH_PORTABLE), *args)
+    assert scene.flat_info()["device_bytes"] > 160 * 1024
+    cam = rt.camera_look((0.0, 20.0, -150.0), (0.0, 0.0, 1.0))
+    e = make_engine(rt, scene, 256, 256, 2, 4, cam)
+    e0 = make_engine(rt, scene, 256, 256, 2, 4, cam, flags=rt.engine.FLAG_NO_CULL)
+    o, d = _culling_stress_rays(obj, rng, 60000)
+    hit, rec = e.trace(o, d)
+    hit0, rec0 = e0.trace(o, d)
+    hit_o, rec_o = osc.trace(o, d)
+    assert (hit >= 0).mean() > 0.5
+    assert_bits(hit, hit0, "ids with and without culling")
+    assert_bits(rec, rec0, "hit records with and without culling")
+    assert_bits(hit, hit_o, "ids vs the oracle")
+    assert_bits(rec[:, 0], rec_o[:, 0], "distances vs the oracle")
+    keys = (np.arange(len(o), dtype=np.uint64) * 2654435761 % (1 << 32)).astype(np.uint32)
+    col = e.ray_color(o, d, 4, keys)
+    assert_bits(col, e0.ray_color(o, d, 4, keys), "radiance with and without culling")
+    assert_bits(col, osc.ray_color(o, d, 4, keys), "radiance vs the oracle")
+    # and it does skip work: a frame's executed slab tests drop well below what the reference algorithm performs
+    a = e.render_frame(5)
+    n_cull = e.stats()["box_tests"]
+    a0 = e0.render_frame(5)
+    n_all = e0.stats()["box_tests"]
+    assert_bits(a, a0, "frame with and without culling")
+    assert 0 < n_cull < 0.7 * n_all, (n_cull, n_all)
+
+
 @pytest.fixture(scope="module")
 def c3_scene(rt, golden):
     """the 100 000-primitive traversal-stress scene at its real size, built through the C ABI"""
@@ -609,7 +687,7 @@ def test_c3_full_frame_properties(rt, golden, c3_scene):
     a = e.render_frame(seed)
     st = e.stats()
     assert st["paths"] == W * H * S * S and st["rays"] > st["paths"]
-    assert e.cfg.max_batch_paths == 1 << 27 and W * H * S * S == 16 << 27
+    assert e.cfg.max_batch_paths == 1 << 27 and -(-W * H * S * S // (1 << 27)) == 16      # 16 batches
     assert (a[..., 0] == 255).all()
     x0, y0, x1, y1 = (int(v) for v in g["crop"])
     assert_frame_close(a[y0:y1, x0:x1], g["crop_rgba"], "C3 full frame, crop region vs the reference")
@@ -619,3 +697,12 @@ def test_c3_full_frame_properties(rt, golden, c3_scene):
     e.set_window(None)
     b = e.render_frame(seed)
     assert_bits(a, b, "two renders of the C3 frame")
+    n_cull, rays = e.stats()["box_tests"], e.stats()["rays"]
+    e.close()
+    # the same frame visiting every box the reference visits
+    e0 = make_engine(rt, scene, W, H, S, B, cam, flags=rt.engine.FLAG_NO_CULL)
+    a0 = e0.render_frame(seed)
+    n_all = e0.stats()["box_tests"]
+    assert_bits(a0, a, "C3 frame without distance culling")
+    print(f"C3 slab tests per ray: {n_cull / rays:.1f} executed with culling, {n_all / rays:.1f} without")
+    assert n_cull < n_all
