@@ -465,6 +465,9 @@ __device__ __forceinline__ void walker_idle(const Scene& sc, Walker& w) {
 //         D (1 + 2^-16 + 2^-23 W) + 2^-16 r_max + W (delta + 2^-22 r_max)  +  W eta' (D + 2 r_max)^2 * rho
 //         \_______________________________ cull_base _________________/     \________ cull_k ________/
 // (margins 2^-16 where 2^-19 would do).  cull_base and cull_k change only when the closest hit does.
+// The planes (tested after the tree, World.cpp:110-118) give no further bound worth having: a box entered beyond a
+// plane lies on its far side, where scenes keep nothing, and a skipped hit there would let the plane be compared with
+// a stale HitInfo.distance where the reference compares it with the hit.
 template <bool CULL>
 __device__ __forceinline__ void cull_start(const Scene& sc, Walker& w, const Ray& ray) {
     w.cull_base = INFINITY; w.cull_k = 0.0f;

@@ -575,14 +575,42 @@ def test_distance_culling_changes_nothing(rt, orc, assets):
     extra[:, 9] = rng.integers(0, 3000, 300)
     obj = np.concatenate([obj, extra])
     plane = [[0.0, len(mat) - 1]]
-    args = (tex, mat, obj, plane, None, None, assets["sky"], 4242)
-    scene = build_table_scene(rt.Scene(), *args)
+    # a build key under which the first leaf of the tree (the one whose rejected HitInfo.distance survives) is a sphere
+    for key in range(4242, 4300):
+        args = (tex, mat, obj, plane, None, None, assets["sky"], key)
+        scene = build_table_scene(rt.Scene(), *args)
+        first = int(scene.dump_top()[3][0])
+        if obj[first, 0] == 0 and obj[first, 4] > 0.3:
+            break
+    else:
+        raise AssertionError("no build key puts a sphere first")
     osc = build_table_scene(orc.Scene(orc.MATH_PORTABLE), *args)
     assert scene.flat_info()["device_bytes"] > 160 * 1024
     cam = rt.camera_look((0.0, 20.0, -150.0), (0.0, 0.0, 1.0))
     e = make_engine(rt, scene, 256, 256, 2, 4, cam)
     e0 = make_engine(rt, scene, 256, 256, 2, 4, cam, flags=rt.engine.FLAG_NO_CULL)
     o, d = _culling_stress_rays(obj, rng, 60000)
+    # rays that leave the first leaf's surface downwards: that sphere writes a negative HitInfo.distance and rejects; many
+    # of these rays cross the plane and then meet the underground part of a large sphere — a hit the plane bound may
+    # skip only if the stale value is honoured (the plane must still win, as in the reference)
+    c0, r0 = obj[first, 1:4].astype(np.float64), float(obj[first, 4])
+    nrm = rng.normal(size=(20000, 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    so = c0 + nrm * r0 * 1.0001
+    sd = nrm + rng.normal(size=(20000, 3)) * 0.7
+    sd[:, 1] = -np.abs(sd[:, 1]) - 0.05
+    sd /= np.linalg.norm(sd, axis=1, keepdims=True)
+    sd32 = sd.astype(np.float32)
+    sd32 /= np.sqrt((sd32.astype(np.float64) ** 2).sum(axis=1, keepdims=True)).astype(np.float32)
+    keep = (sd32.astype(np.float64) * nrm).sum(axis=1) > 0.05            # pointing away from the sphere
+    so, sd32 = so[keep].astype(np.float32), sd32[keep]
+    osc_np = build_table_scene(orc.Scene(orc.MATH_PORTABLE), tex, mat, obj, np.zeros((0, 2), np.float32), None, None, assets["sky"], key)
+    hit_np, rec_np = osc_np.trace(so, sd32)
+    t_plane = -(so[:, 1] - np.float32(0.001)) / sd32[:, 1]
+    n_trap = int(((hit_np >= 0) & (rec_np[:, 0] > t_plane * 1.01) & (t_plane > 0.001)).sum())
+    assert n_trap > 50, f"only {n_trap} rays have their only hits beyond the plane"
+    assert ((osc.trace(so, sd32)[0] == -1) & (osc.trace(so, sd32)[1][:, 0] < 0)).sum() > 50     # stale values do occur
+    o, d = np.concatenate([o, so]), np.concatenate([d, sd32])
     hit, rec = e.trace(o, d)
     hit0, rec0 = e0.trace(o, d)
     hit_o, rec_o = osc.trace(o, d)
