@@ -6,7 +6,11 @@ cut into image tiles across the N ranks and the tiles gathered to rank 0 over RC
 (one World::GetRayColor invocation of the reference).  Scene, camera and queues are resident in HBM before the timed
 region; nothing is read from the host inside it.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c1|c3] [--no-cpu-baseline]
+The headline line is the C2 workload (default scene, 1920x1080, 64 spp, 8 bounces).  The default invocation then runs,
+in the same process, the traversal-stress scene at its full size (C3; with N > 1 ranks this is C4) and the interactive
+camera path (C5, every frame waited for and copied to page-locked host memory) and appends them as "also".
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c1|c3|c5] [--no-cpu-baseline] [--no-also]
     N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
@@ -21,17 +25,21 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 BUILD_KEY = 0x5EED0001
+# the reference's tree depends on the random axis it draws per node (Object.cpp:191), so its cost per ray depends on the
+# build key; the headline uses BUILD_KEY, the line also reports these to show the spread
+SPREAD_KEYS = (0x5EED0001, 0x00C0FFEE, 0x12345678)
 SEED = 7
 CAM_DEFAULT = ((0.0, 3.0, -10.0), (0.0, 0.0, 1.0))          # World.cpp:48
+CAM_SYNTHETIC = ((0.0, 20.0, -150.0), (0.0, 0.0, 1.0))
 WORKLOADS = {
     # name: (description, W, H, S, B)
     "c1": ("default scene 1280x720, 9 spp, 3 bounces (the reference's Constants.h)", 1280, 720, 3, 3),
     "c2": ("default scene 1920x1080, 64 spp, 8 bounces", 1920, 1080, 8, 8),
     "c3": ("synthetic 100k sphere/box scene 3840x2160, 256 spp, 8 bounces", 3840, 2160, 16, 8),
     # interactive sequence: the camera moves every frame as the front end's input handler would move it (App.cpp:98,
-    # 114-137: mouse (3, 1) per frame, key W for frames 0-119, D for 120-239); every frame is waited for, so a step's
-    # time is the latency a viewer sees, gather included
-    "c5": ("default scene 1920x1080, 9 spp, 3 bounces, 240-frame camera path, one frame in flight", 1920, 1080, 3, 3),
+    # 114-137: mouse (3, 1) per frame, key W for frames 0-119, D for 120-239); every frame is waited for and handed to the
+    # host the way the front end takes it (FrameManager.cpp:60-71 + App.cpp:75), so a step's time is what a viewer sees
+    "c5": ("default scene 1920x1080, 9 spp, 3 bounces, 240-frame camera path, one frame in flight, frame copied to the host", 1920, 1080, 3, 3),
 }
 # FLOPs the reference algorithm spends per counted event (sqrt and divide count 1, compares and libm calls excluded).
 # The events of the closest-hit query (and, for primary rays, camera-ray generation) are the work of intersect_kernel,
@@ -51,18 +59,42 @@ PEAK_HBM_GBS = 8000.0
 # used when the CPU leg is skipped (--no-cpu-baseline, N > 1)
 FALLBACK_FLOP_PER_RAY = {"c1": 1002.0, "c2": 1002.0, "c3": 7000.0, "c5": 1002.0}
 FALLBACK_SCENE_BYTE_PER_RAY = {"c1": 1480.0, "c2": 1480.0, "c3": 13400.0, "c5": 1480.0}
+FALLBACK_BOX_PER_RAY = {"c1": 39.2, "c2": 39.2, "c3": 393.0, "c5": 39.2}
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r2_c2_pmc_summary.txt")
 
 
-def build_scene(rt, workload):
+def build_scene(rt, workload, key=BUILD_KEY):
+    """(scene, camera, seconds inside rt_scene_build): the tree construction of BVH_Node::BVH_Node (Object.cpp:181-225)
+    plus flattening; asset decoding and the per-object calls from Python are not in the figure"""
     if workload in ("c1", "c2", "c5"):
-        return rt.default_scene(BUILD_KEY), rt.camera_look(*CAM_DEFAULT)
-    from raytracer_amd.synthetic import synthetic_scene
-    return synthetic_scene(rt, 100000, BUILD_KEY + 2), rt.camera_look((0.0, 20.0, -150.0), (0.0, 0.0, 1.0))
+        s = rt.Scene()
+        s.default_objects()
+        t0 = time.perf_counter()
+        s.build(key)
+        return s, rt.camera_look(*CAM_DEFAULT), time.perf_counter() - t0
+    from raytracer_amd.synthetic import synthetic_tables
+
+    class Timed:                                     # build_from_tables ends with S.build(key): time just that call
+        def __init__(self, s):
+            self.s, self.seconds = s, 0.0
+
+        def __getattr__(self, name):
+            return getattr(self.s, name)
+
+        def build(self, k):
+            t0 = time.perf_counter()
+            self.s.build(k)
+            self.seconds = time.perf_counter() - t0
+    from raytracer_amd.synthetic import build_from_tables
+    E = rt.engine
+    sky, _ = E.load_png(os.path.join(E.ASSET_DIR, "src", "stb_image", "skybox12.png"), 3)
+    obj, tex, mat = synthetic_tables(100000)
+    t = Timed(rt.Scene())
+    build_from_tables(t, tex, mat, obj, [[0.0, len(mat) - 1]], sky, key + 2)
+    return t.s, rt.camera_look(*CAM_SYNTHETIC), t.seconds
 
 
-def cpu_baseline(workload, W, H, S, B, threads):
-    """the CPU restatement of the reference (oracle/, libm math like the reference) on a bounded sample of the workload:
-    horizontal strips spread over the frame, every sample and bounce of their pixels"""
+def oracle_scene(workload, key=BUILD_KEY):
     from oracle import orcbind as O
     import raytracer_amd as rt
     E = rt.engine
@@ -73,80 +105,309 @@ def cpu_baseline(workload, W, H, S, B, threads):
         verts = E.load_obj(os.path.join(asset, "tree.obj"))
         tex, _ = E.load_png(os.path.join(asset, "tree_texture.png"), 4)
         s.default_scene(verts, tex, sky)
-        s.build(BUILD_KEY)
-        cam = O.camera(*CAM_DEFAULT)
-    else:
-        from raytracer_amd.synthetic import synthetic_tables, build_from_tables
-        obj, tex_t, mat_t = synthetic_tables(100000)
-        build_from_tables(s, tex_t, mat_t, obj, [[0.0, len(mat_t) - 1]], sky, BUILD_KEY + 2)
-        cam = O.camera((0.0, 20.0, -150.0), (0.0, 0.0, 1.0))
-    # sized for roughly 10-30 s on 16 host threads: the whole frame for c1/c2, a few row segments for c3
-    n_strips, rows = {"c1": (1, H), "c2": (1, H), "c3": (4, 1), "c5": (1, H)}[workload]
+        s.build(key)
+        return s, O.camera(*CAM_DEFAULT)
+    from raytracer_amd.synthetic import synthetic_tables, build_from_tables
+    obj, tex_t, mat_t = synthetic_tables(100000)
+    build_from_tables(s, tex_t, mat_t, obj, [[0.0, len(mat_t) - 1]], sky, key + 2)
+    return s, O.camera(*CAM_SYNTHETIC)
+
+
+def per_ray_figures(c):
+    flops = sum(FLOP_INTERSECT[k] * c[k] for k in FLOP_INTERSECT)
+    flops_shade = sum(FLOP_SHADE[k] * c[k] for k in FLOP_SHADE)
+    nbytes = sum(SCENE_BYTE_WEIGHTS[k] * c[k] for k in SCENE_BYTE_WEIGHTS)
+    return {"intersect_flop_per_ray": flops / c["rays"], "shade_flop_per_ray": flops_shade / c["rays"],
+            "scene_byte_per_ray": nbytes / c["rays"], "rays_per_sample": c["rays"] / c["samples"],
+            "box_tests_per_ray": c["aabb"] / c["rays"]}
+
+
+def cpu_baseline(workload, W, H, S, B, threads):
+    """the CPU restatement of the reference (oracle/, libm math like the reference) on a bounded sample of the workload:
+    horizontal strips spread over the frame, every sample and bounce of their pixels"""
+    s, cam = oracle_scene(workload)
+    # sized for roughly 10-30 s on 16 host threads: the whole frame for c1/c2; for c3 32 one-row segments of 240 pixels
+    # spread over the frame's height and width, all 256 samples of each pixel
+    n_strips, rows = {"c1": (1, H), "c2": (1, H), "c3": (32, 1), "c5": (1, H)}[workload]
     s.counters(reset=True)
     t0 = time.perf_counter()
     px = 0
     for k in range(n_strips):
         y0 = int((k + 0.5) * H / n_strips) if rows < H else 0
         x1 = W if workload != "c3" else W // 16
-        s.render(cam, W, H, S, B, SEED, rect=(0, y0, x1, min(H, y0 + rows)), threads=threads, want=("rgba",))
+        x0 = 0 if workload != "c3" else k * W // n_strips
+        s.render(cam, W, H, S, B, SEED, rect=(x0, y0, x0 + x1, min(H, y0 + rows)), threads=threads, want=("rgba",))
         px += x1 * (min(H, y0 + rows) - y0)
     dt = time.perf_counter() - t0
     c = s.counters()
-    # the reference's own thread count (THREAD_COUNT 7, Constants.h:6) on 16 strips of 8 rows (c3: one segment)
-    t0 = time.perf_counter()
-    for k in range(16 if workload != "c3" else 1):
-        y0 = int((k + 0.5) * H / 16)
-        s.render(cam, W, H, S, B, SEED, rect=(0, y0, W if workload != "c3" else W // 16, min(H, y0 + (8 if workload != "c3" else 1))),
-                 threads=7, want=("rgba",))
-    dt7 = time.perf_counter() - t0
-    rays7 = s.counters()["rays"] - c["rays"]
-    flops = sum(FLOP_INTERSECT[k] * c[k] for k in FLOP_INTERSECT)
-    flops_shade = sum(FLOP_SHADE[k] * c[k] for k in FLOP_SHADE)
-    nbytes = sum(SCENE_BYTE_WEIGHTS[k] * c[k] for k in SCENE_BYTE_WEIGHTS)
-    return {"value": c["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-            "value_7_threads": rays7 / dt7 / 1e6,
-            "sample": f"{n_strips} strips x {rows} rows = {px} pixels of the {W}x{H} frame, all {S * S} spp and {B} bounces, "
-                      f"{c['rays']} rays in {dt:.1f} s; contiguous pixel ranges per thread as FrameManager.cpp:80-82",
-            "intersect_flop_per_ray": flops / c["rays"], "shade_flop_per_ray": flops_shade / c["rays"],
-            "scene_byte_per_ray": nbytes / c["rays"], "rays_per_sample": c["rays"] / c["samples"]}
+    # a smaller sample for the side figures: 16 strips of 8 rows (c3: every fourth segment of the sample above), with the
+    # reference's own thread count (THREAD_COUNT 7, Constants.h:6) and with `threads`
+    def strips(n_threads):
+        before = s.counters()["rays"]
+        t0 = time.perf_counter()
+        if workload == "c3":
+            for k in range(0, n_strips, 4):
+                y0, x0 = int((k + 0.5) * H / n_strips), k * W // n_strips
+                s.render(cam, W, H, S, B, SEED, rect=(x0, y0, x0 + W // 16, y0 + 1), threads=n_threads, want=("rgba",))
+        else:
+            for k in range(16):
+                y0 = int((k + 0.5) * H / 16)
+                s.render(cam, W, H, S, B, SEED, rect=(0, y0, W, min(H, y0 + 8)), threads=n_threads, want=("rgba",))
+        return (s.counters()["rays"] - before) / (time.perf_counter() - t0) / 1e6
+    v7 = strips(7)
+    v_strips = strips(threads)
+    out = {"value": c["rays"] / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+           "value_7_threads": v7, "value_on_16_strips": v_strips,
+           "sample": f"{n_strips} strips x {rows} rows = {px} pixels of the {W}x{H} frame, all {S * S} spp and {B} bounces, "
+                     f"{c['rays']} rays in {dt:.1f} s; contiguous pixel ranges per thread as FrameManager.cpp:80-82"}
+    out.update(per_ray_figures(c))
+    # the compiled reference itself (oracle/_ref/libref.so: the reference's own sources behind a harness), where it travelled
+    # with the tree: the default scene only (its World builds that scene), 16 strips of 8 rows
+    if workload != "c3":
+        try:
+            from oracle.refbind import Ref, available
+            if available():
+                R = Ref()
+                w = R.world(BUILD_KEY)
+                t0 = time.perf_counter()
+                n_px = 0
+                for k in range(16):
+                    y0 = int((k + 0.5) * H / 16)
+                    R.render(w, W, H, S, B, SEED, rect=(0, y0, W, min(H, y0 + 8)), threads=threads, want=("rgba",))
+                    n_px += W * (min(H, y0 + 8) - y0)
+                dtr = time.perf_counter() - t0
+                R.free(w)
+                out["reference"] = {"value": n_px * S * S * out["rays_per_sample"] / dtr / 1e6, "unit": "Mrays/s", "cores": threads,
+                                    "kind": "reference", "sample": f"16 strips x 8 rows = {n_px} pixels in {dtr:.1f} s (compare value_on_16_strips); rays = "
+                                    "samples x the oracle's rays per sample (the reference's code has no ray counter)"}
+        except Exception as ex:      # the compiled reference is optional test infrastructure
+            out["reference"] = {"error": str(ex)[:200]}
+    return out
 
 
-def pmc_traffic(path, kernel):
-    """HBM bytes per frame of one kernel from a summary written by tools/pmc_summary.py (separate rocprofv3 --pmc runs of
-    this same command): FETCH_SIZE and WRITE_SIZE are in units of 1 KiB, and on gfx950 FETCH_SIZE counts half
-    of the bytes read, so  bytes = 1024 * (2 * FETCH_SIZE + WRITE_SIZE), summed over the kernel's template variants."""
+def key_spread(rt, eng, tr, W, H, S, B, with_cpu):
+    """the headline workload under three build keys: the reference's random-axis tree makes the cost per ray depend on the
+    key, so one key's Mrays/s (and roofline fraction) is one sample of a spread"""
+    import torch
+    rows = []
+    for key in SPREAD_KEYS:
+        scene, cam, _ = build_scene(rt, "c2", key)
+        eng.set_scene(scene)
+        eng.set_camera(cam)
+        tr.render_frame(SEED)
+        torch.cuda.synchronize()
+        eng.time_kernels(True)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            tr.render_frame(SEED)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / 3 * 1e3
+        kern_ms, _ = eng.kernel_times()
+        eng.time_kernels(False)
+        st = eng.stats()
+        row = {"build_key": f"0x{key:08X}", "ms_per_frame": ms, "mrays_per_s": st["rays"] / ms / 1e3,
+               "intersect_kernel_ms": kern_ms, "executed_box_tests_per_ray": st["box_tests"] / st["rays"]}
+        if with_cpu:
+            s, ocam = oracle_scene("c2", key)
+            s.counters(reset=True)
+            for k in range(8):
+                y0 = int((k + 0.5) * H / 8)
+                s.render(ocam, W, H, S, B, SEED, rect=(0, y0, W, y0 + 2), threads=with_cpu, want=("rgba",))
+            f = per_ray_figures(s.counters())
+            tf = f["intersect_flop_per_ray"] * st["rays"] / (kern_ms / 1e3) / 1e12
+            # under BUILD_KEY the tree (a mesh instance) is the only object of its node, so the reference walks the
+            # whole mesh twice per ray (Object.cpp:198-200: left == right) and the algorithmic figure counts both walks;
+            # the engine walks it once, which is why its executed count is far below the algorithmic one for this key
+            row.update({"flop_per_ray": f["intersect_flop_per_ray"], "box_tests_per_ray": f["box_tests_per_ray"],
+                        "roofline_achieved_tflops": tf, "roofline_frac": tf / PEAK_FP32_TFLOPS})
+        rows.append(row)
+    return rows
+
+
+def pmc_summary(path, kernel):
+    """(source hash, HBM bytes per frame, active-lane fractions) of one kernel from a summary written by
+    tools/pmc_summary.py (separate rocprofv3 --pmc runs of this same command): FETCH_SIZE and WRITE_SIZE are in units of
+    1 KiB, and on gfx950 FETCH_SIZE counts half of the bytes read, so  bytes = 1024 * (2 * FETCH_SIZE + WRITE_SIZE),
+    summed over the kernel's template variants."""
     try:
         lines = open(path).read().splitlines()
     except OSError:
-        return None
-    total, inside, seen = 0.0, False, False
+        return None, None, None
+    src, total, inside, seen, lanes, name = None, 0.0, False, False, {}, None
     for ln in lines:
-        if not ln.startswith(" "):
+        if ln.startswith("source_hash:"):
+            src = ln.split(":", 1)[1].strip()
+        elif not ln.startswith(" "):
             inside = ln.startswith(kernel)
-            continue
-        if inside:
-            name, val = ln.split()[:2]
-            if name == "FETCH_SIZE":
-                total += 2048.0 * float(val); seen = True
-            elif name == "WRITE_SIZE":
-                total += 1024.0 * float(val); seen = True
-    return total if seen else None
+            name = ln.split("  dispatches")[0] if inside else None
+        elif inside:
+            f = ln.split()
+            if f[0] == "FETCH_SIZE":
+                total += 2048.0 * float(f[1]); seen = True
+            elif f[0] == "WRITE_SIZE":
+                total += 1024.0 * float(f[1]); seen = True
+            elif f[:2] == ["active-lane", "fraction"]:
+                lanes[name] = float(f[2])
+    return src, (total if seen else None), (lanes or None)
 
 
-def pmc_active_lanes(path, kernel):
-    """Active-lane fraction SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU) per template variant of a kernel, from the
-    same summary."""
-    try:
-        lines = open(path).read().splitlines()
-    except OSError:
-        return None
-    out, name = {}, None
-    for ln in lines:
-        if not ln.startswith(" "):
-            name = ln.split("  dispatches")[0] if ln.startswith(kernel) else None
-        elif name and ln.split()[:2] == ["active-lane", "fraction"]:
-            out[name] = float(ln.split()[2])
-    return out or None
+class Job:
+    """process-group plumbing shared by the workloads of one invocation"""
+
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        if self.world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={self.world}: launch N>1 with torch.distributed.run --nproc-per-node N")
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU: the HIP engine is the only compute path")
+        self.rehearsal = args.rehearse_on_one_gpu
+        if self.rehearsal:
+            self.local_rank = 0
+        torch.cuda.set_device(self.local_rank)
+        self.device = torch.device("cuda", self.local_rank)
+        self.red_device = torch.device("cpu") if self.rehearsal else self.device     # where the timing reductions live
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.rehearsal:
+                dist.init_process_group("gloo", rank=self.rank, world_size=self.world)
+            else:
+                dist.init_process_group("nccl", rank=self.rank, world_size=self.world, device_id=self.device)
+
+    def barrier(self):
+        self.torch.cuda.synchronize(self.device)
+        if self.world > 1:
+            self.dist.barrier()
+            self.torch.cuda.synchronize(self.device)
+
+    def reduce(self, values, op):
+        t = self.torch.tensor(values, dtype=self.torch.float64, device=self.red_device)
+        if self.world > 1:
+            self.dist.all_reduce(t, op=getattr(self.dist.ReduceOp, op))
+        return [float(v) for v in t]
+
+    def gather_all(self, values):
+        """every rank's values, as a list per value (rank order)"""
+        t = self.torch.tensor(values, dtype=self.torch.float64, device=self.red_device)
+        if self.world == 1:
+            return [[float(v)] for v in t]
+        parts = [self.torch.zeros_like(t) for _ in range(self.world)]
+        self.dist.all_gather(parts, t)
+        return [[float(p[i]) for p in parts] for i in range(len(values))]
+
+    def close(self):
+        if self.world > 1:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def run_workload(job, rt, workload, steps, warmup, batch_paths=0):
+    """warm up, then time `steps` frames between barriers; returns this rank's measurements plus the reductions"""
+    from raytracer_amd.distributed import TileRenderer
+    desc, W, H, S, B = WORKLOADS[workload]
+    scene, cam, build_s = build_scene(rt, workload)
+    eng = rt.Engine(rt.default_config(width=W, height=H, samples_per_axis=S, bounces=B, device=job.local_rank,
+                                      max_batch_paths=batch_paths))
+    eng.set_scene(scene)
+    eng.set_camera(cam)
+    tr = TileRenderer(eng, job.device, job.rank, job.world)
+    frame_ms = []
+    for _ in range(warmup):
+        tr.render_frame(SEED)
+    job.barrier()
+    eng.time_kernels(True)
+    t0 = time.perf_counter()
+    if workload == "c5":
+        for f in range(steps):
+            cam = rt.camera_input(cam, 3.0, 1.0, w=int(f % 240 < 120), d=int(f % 240 >= 120))
+            eng.set_camera(cam)
+            t1 = time.perf_counter()
+            if job.world == 1:
+                # one GPU: the engine's own frame buffer, handed over through its page-locked host copy
+                # (rt_engine_map_frame: the copy runs on the render's stream right behind it)
+                eng.render(SEED + f)
+                eng.map_frame(wait=True)
+            else:
+                frame = tr.render_frame(SEED + f)
+                job.barrier()
+                if frame is not None:
+                    frame.cpu()
+            frame_ms.append((time.perf_counter() - t1) * 1e3)
+    else:
+        for _ in range(steps):
+            tr.render_frame(SEED)
+    job.barrier()
+    dt = time.perf_counter() - t0
+    kern_ms, kern_launches = eng.kernel_times()
+    eng.time_kernels(False)
+    st = eng.stats()                       # this rank's share of one frame (every step renders the same frame)
+    dt = job.reduce([dt], "MAX")[0]
+    rays_frame, paths_frame, box_frame = job.reduce([st["rays"], st["paths"], st["box_tests"]], "SUM")
+    per_rank = job.gather_all([st["rays"], kern_ms, kern_launches])
+    return {"desc": desc, "W": W, "H": H, "S": S, "B": B, "eng": eng, "tr": tr, "dt": dt, "steps": steps, "frame_ms": frame_ms,
+            "kern_ms": max(per_rank[1]), "kern_launches": kern_launches, "stats": st, "rays_frame": rays_frame,
+            "paths_frame": paths_frame, "box_frame": box_frame, "per_rank": per_rank, "scene_build_s": build_s}
+
+
+def c5_on_one_gpu(job, rt, steps):
+    """C5 on one GPU without the tile renderer in between: render into the engine's own frame buffer and take the frame
+    from its page-locked host copy, as the front-end adapter does"""
+    desc, W, H, S, B = WORKLOADS["c5"]
+    scene, cam, _ = build_scene(rt, "c5")
+    eng = rt.Engine(rt.default_config(width=W, height=H, samples_per_axis=S, bounces=B, device=job.local_rank))
+    eng.set_scene(scene)
+    eng.set_camera(cam)
+    for _ in range(3):
+        eng.render(SEED)
+        eng.map_frame(wait=True)
+    render_ms, total_ms = [], []
+    for f in range(steps):
+        cam = rt.camera_input(cam, 3.0, 1.0, w=int(f % 240 < 120), d=int(f % 240 >= 120))
+        eng.set_camera(cam)
+        t1 = time.perf_counter()
+        eng.render(SEED + f)
+        eng.sync()
+        t2 = time.perf_counter()
+        eng.map_frame(wait=True)
+        t3 = time.perf_counter()
+        render_ms.append((t2 - t1) * 1e3)
+        total_ms.append((t3 - t1) * 1e3)
+    eng.close()
+    pct = lambda v, q: float(np.percentile(v, q))
+    return {"workload": desc, "frames": steps, "includes": "render + device-to-host copy of the frame into page-locked memory (8.3 MB)",
+            "frame_latency_ms": {"p50": pct(total_ms, 50), "p99": pct(total_ms, 99), "max": float(max(total_ms))},
+            "render_only_ms": {"p50": pct(render_ms, 50), "p99": pct(render_ms, 99)}}
+
+
+def roofline_of(r, workload, cpu):
+    flop_per_ray = cpu["intersect_flop_per_ray"] if cpu else FALLBACK_FLOP_PER_RAY[workload]
+    scene_byte_per_ray = cpu["scene_byte_per_ray"] if cpu else FALLBACK_SCENE_BYTE_PER_RAY[workload]
+    box_per_ray = cpu["box_tests_per_ray"] if cpu else FALLBACK_BOX_PER_RAY[workload]
+    # dominant kernel = intersect_kernel (one launch per bounce level and batch); the launches of the last timed frame on
+    # the slowest rank, measured with HIP events on the render stream; every step renders the same frame
+    kern_s = r["kern_ms"] / 1e3
+    st, n = r["stats"], r["kern_launches"]
+    ach_tflops = flop_per_ray * st["rays"] / kern_s / 1e12 if kern_s > 0 else None
+    stream_bytes = HIT_WRITE_BYTES * st["rays"] + RAY_READ_BYTES * (st["rays"] - st["paths"])
+    ach_gbs = stream_bytes / kern_s / 1e9 if kern_s > 0 else None
+    roof = {"bound": "valu", "achieved": ach_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+            "frac": (ach_tflops / PEAK_FP32_TFLOPS) if ach_tflops else None, "traffic": None,
+            # the reference's unfused, unpacked arithmetic (kept for bit-exact ids) can issue 1/4 of the peak
+            "frac_of_unfused_peak": (ach_tflops / (PEAK_FP32_TFLOPS / 4)) if ach_tflops else None,
+            "kernel": "intersect_kernel", "launches": n, "avg_launch_ms": (r["kern_ms"] / n) if n else None,
+            "flop_per_ray": flop_per_ray, "rays_per_launch": st["rays"] / n if n else None,
+            # slab tests: what the reference algorithm performs for these rays (the figure `achieved` is computed from) and
+            # what the engine executed (fewer where it skips boxes behind the closest hit)
+            "box_tests_per_ray": {"algorithmic": box_per_ray, "executed": st["box_tests"] / st["rays"] if st["rays"] else None}}
+    hbm = {"bound": "hbm", "achieved": ach_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": (ach_gbs / PEAK_HBM_GBS) if ach_gbs else None,
+           "traffic": None, "algorithmic_bytes_per_launch": stream_bytes / n if n else None,
+           "stream_byte_per_ray": stream_bytes / st["rays"] if st["rays"] else None,
+           "scene_byte_per_ray": scene_byte_per_ray}
+    return roof, hbm
 
 
 def main():
@@ -156,6 +417,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="only the headline workload (profiling runs)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--batch-paths", type=int, default=0)
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -163,129 +425,83 @@ def main():
                          "path on a one-GPU box; the number it prints is not a measurement")
     args = ap.parse_args()
 
-    import torch
-    import torch.distributed as dist
     import raytracer_amd as rt
-    from raytracer_amd.distributed import TileRenderer
+    job = Job(args)
+    rank, world = job.rank, job.world
+    threads = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))
+    with_cpu = (not args.no_cpu_baseline) and world == 1
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run --nproc-per-node N")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the HIP engine is the only compute path")
-    if args.rehearse_on_one_gpu:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    red_device = torch.device("cpu") if args.rehearse_on_one_gpu else device     # where the timing reductions live
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.rehearse_on_one_gpu:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
-        else:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-
-    desc, W, H, S, B = WORKLOADS[args.workload]
-    scene, cam = build_scene(rt, args.workload)
-    eng = rt.Engine(rt.default_config(width=W, height=H, samples_per_axis=S, bounces=B, device=local_rank,
-                                      max_batch_paths=args.batch_paths))
-    eng.set_scene(scene)
-    eng.set_camera(cam)
-    tr = TileRenderer(eng, device, rank, world)
-
-    def barrier():
-        torch.cuda.synchronize(device)
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize(device)
-
-    frame_ms = []
-    for _ in range(args.warmup):
-        tr.render_frame(SEED)
-    barrier()
-    eng.time_kernels(True)
-    t0 = time.perf_counter()
-    if args.workload == "c5":
-        for f in range(args.steps):
-            cam = rt.camera_input(cam, 3.0, 1.0, w=int(f % 240 < 120), d=int(f % 240 >= 120))
-            eng.set_camera(cam)
-            t1 = time.perf_counter()
-            tr.render_frame(SEED + f)
-            barrier()
-            frame_ms.append((time.perf_counter() - t1) * 1e3)
-    else:
-        for _ in range(args.steps):
-            tr.render_frame(SEED)
-    barrier()
-    dt = time.perf_counter() - t0
-    kern_ms, kern_launches = eng.kernel_times()
-    eng.time_kernels(False)
-    st = eng.stats()                       # this rank's share of one frame (every step renders the same frame)
-
-    t = torch.tensor([dt], dtype=torch.float64, device=red_device)
-    counts = torch.tensor([st["rays"], st["paths"]], dtype=torch.float64, device=red_device)
-    kt = torch.tensor([kern_ms], dtype=torch.float64, device=red_device)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
-        dist.all_reduce(kt, op=dist.ReduceOp.MAX)
-    dt = float(t[0])
-    rays_frame, paths_frame = float(counts[0]), float(counts[1])
+    r = run_workload(job, rt, args.workload, args.steps, args.warmup, args.batch_paths)
+    desc, W, H, S, B = r["desc"], r["W"], r["H"], r["S"], r["B"]
+    out = None
     if rank == 0:
-        cpu = None
-        if not args.no_cpu_baseline and world == 1:
-            threads = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))
-            cpu = cpu_baseline(args.workload, W, H, S, B, threads)
-        flop_per_ray = cpu["intersect_flop_per_ray"] if cpu else FALLBACK_FLOP_PER_RAY[args.workload]
-        scene_byte_per_ray = cpu["scene_byte_per_ray"] if cpu else FALLBACK_SCENE_BYTE_PER_RAY[args.workload]
-        value = rays_frame * args.steps / dt / 1e6
-        # dominant kernel = intersect_kernel (one launch per bounce level); the launches of the last timed frame on the
-        # slowest rank, measured with HIP events on the render stream; every step renders the same frame
-        kern_s = float(kt[0]) / 1e3
-        rays_rank0 = st["rays"]
-        ach_tflops = flop_per_ray * rays_rank0 / kern_s / 1e12 if kern_s > 0 else None
-        stream_bytes = HIT_WRITE_BYTES * st["rays"] + RAY_READ_BYTES * (st["rays"] - st["paths"])
-        ach_gbs = stream_bytes / kern_s / 1e9 if kern_s > 0 else None
-        # measured HBM traffic of the same kernel: PMC passes cannot run inside this process, so the figure comes from the
-        # committed summary of tools/profile.sh runs of this command (C2, one GPU) and is null for anything else
-        traffic, lanes = None, None
-        if args.workload == "c2" and world == 1 and kern_launches:
-            per_frame = pmc_traffic(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_c2_pmc_summary.txt"),
-                                    "intersect_kernel")
-            traffic = per_frame / kern_launches if per_frame else None
-            lanes = pmc_active_lanes(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_c2_pmc_summary.txt"),
-                                     "intersect_kernel")
+        cpu = cpu_baseline(args.workload, W, H, S, B, threads) if with_cpu else None
+        roof, hbm = roofline_of(r, args.workload, cpu)
+        # measured HBM traffic and lane use of the same kernel: PMC passes cannot run inside this process, so the figures
+        # come from the committed summary of tools/profile.sh runs of this command (C2, one GPU) — and only if that
+        # summary was taken from the very kernel sources this library was compiled from
+        note = "no PMC summary for this workload"
+        if args.workload == "c2" and world == 1 and r["kern_launches"]:
+            src, per_frame, lanes = pmc_summary(PMC_SUMMARY, "intersect_kernel")
+            have = rt.engine.source_hash()
+            if src is None:
+                note = f"{os.path.relpath(PMC_SUMMARY, ROOT)} not found"
+            elif src != have:
+                note = f"{os.path.relpath(PMC_SUMMARY, ROOT)} was taken from kernel sources {src}, this library is {have}: not reported"
+            else:
+                roof["traffic"] = hbm["traffic"] = per_frame / r["kern_launches"] if per_frame else None
+                roof["active_lane_fraction"] = lanes
+                note = f"bytes per launch, PMC, {os.path.relpath(PMC_SUMMARY, ROOT)} (kernel sources {src})"
+        roof["traffic_note"] = hbm["traffic_note"] = note
+        value = r["rays_frame"] * args.steps / r["dt"] / 1e6
+        fm = r["frame_ms"]
         out = {
             "metric": "Mrays/s", "value": value, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": r["dt"] / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic" if not args.rehearse_on_one_gpu else "synthetic (rehearsal: all ranks on one GPU, not a measurement)",
-            "config": {"workload": desc, "width": W, "height": H, "spp": S * S, "bounces": B, "rays_per_frame": rays_frame,
-                       "paths_per_frame": paths_frame, "parallelism": f"tiles{world}", "batch_paths": eng.cfg.max_batch_paths},
-            "ms_per_frame": dt / args.steps * 1e3,
-            "frame_latency_ms": ({"p50": float(np.percentile(frame_ms, 50)), "p99": float(np.percentile(frame_ms, 99)),
-                                  "max": float(max(frame_ms))} if frame_ms else None),
-            "roofline": {"bound": "valu", "achieved": ach_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": (ach_tflops / PEAK_FP32_TFLOPS) if ach_tflops else None, "traffic": traffic,
-                         # the reference's unfused, unpacked arithmetic (kept for bit-exact ids) can issue 1/4 of the peak
-                         "frac_of_unfused_peak": (ach_tflops / (PEAK_FP32_TFLOPS / 4)) if ach_tflops else None,
-                         "kernel": "intersect_kernel", "launches": kern_launches,
-                         "avg_launch_ms": (float(kt[0]) / kern_launches) if kern_launches else None,
-                         "active_lane_fraction": lanes, "flop_per_ray": flop_per_ray, "rays_per_launch": rays_rank0 / kern_launches if kern_launches else None},
-            # the same kernel against HBM: ray records in, hit records out (the scene itself is read from LDS)
-            "roofline_hbm": {"bound": "hbm", "achieved": ach_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                             "frac": (ach_gbs / PEAK_HBM_GBS) if ach_gbs else None, "traffic": traffic,
-                             "traffic_unit": "bytes per launch (PMC, profiles/r1_c2_pmc_summary.txt)",
-                             "algorithmic_bytes_per_launch": stream_bytes / kern_launches if kern_launches else None,
-                             "stream_byte_per_ray": stream_bytes / rays_rank0 if rays_rank0 else None,
-                             "scene_byte_per_ray_from_lds": scene_byte_per_ray},
-            "cpu_baseline": cpu,
+            "config": {"workload": desc, "width": W, "height": H, "spp": S * S, "bounces": B, "rays_per_frame": r["rays_frame"],
+                       "paths_per_frame": r["paths_frame"], "parallelism": f"tiles{world}", "batch_paths": r["eng"].cfg.max_batch_paths,
+                       "build_key": f"0x{BUILD_KEY:08X}", "scene_build_s": r["scene_build_s"], "kernel_sources": rt.engine.source_hash()},
+            "ms_per_frame": r["dt"] / args.steps * 1e3,
+            "frame_latency_ms": ({"p50": float(np.percentile(fm, 50)), "p99": float(np.percentile(fm, 99)), "max": float(max(fm))} if fm else None),
+            "roofline": roof, "roofline_hbm": hbm, "cpu_baseline": cpu,
+            # what each rank did in the last frame: with tiles interleaved the rays should be even; the slowest rank's
+            # kernel time against the step time shows what the gather and the launch gaps cost
+            "per_rank": {"rays": r["per_rank"][0], "intersect_kernel_ms": r["per_rank"][1],
+                         "rays_min_max": [min(r["per_rank"][0]), max(r["per_rank"][0])],
+                         "intersect_kernel_ms_min_max": [min(r["per_rank"][1]), max(r["per_rank"][1])]},
         }
+    if args.workload == "c2" and not args.no_also:
+        if world == 1:
+            spread = key_spread(rt, r["eng"], r["tr"], W, H, S, B, threads if with_cpu else 0)
+            if out is not None:
+                out["build_key_spread"] = spread
+        r["eng"].close()
+        also = {}
+        r3 = run_workload(job, rt, "c3", 2, 1)
+        if rank == 0:
+            cpu3 = cpu_baseline("c3", r3["W"], r3["H"], r3["S"], r3["B"], threads) if with_cpu else None
+            roof3, _ = roofline_of(r3, "c3", cpu3)
+            also["c3"] = {"workload": r3["desc"] + (f", tiles over {world} GPUs (C4)" if world > 1 else ""), "steps": 2, "warmup": 1,
+                          "ms_per_frame": r3["dt"] / 2 * 1e3, "mrays_per_s": r3["rays_frame"] * 2 / r3["dt"] / 1e6,
+                          "rays_per_frame": r3["rays_frame"], "scene_build_s": r3["scene_build_s"], "roofline": roof3, "cpu_baseline": cpu3,
+                          "per_rank": {"rays_min_max": [min(r3["per_rank"][0]), max(r3["per_rank"][0])],
+                                       "intersect_kernel_ms_min_max": [min(r3["per_rank"][1]), max(r3["per_rank"][1])]}}
+        r3["eng"].close()
+        if world == 1:
+            also["c5"] = c5_on_one_gpu(job, rt, 240)
+        else:
+            r5 = run_workload(job, rt, "c5", 240, 3)
+            if rank == 0:
+                fm = r5["frame_ms"]
+                also["c5"] = {"workload": r5["desc"], "frames": 240, "includes": "render + tile gather + device-to-host copy on the display rank",
+                              "frame_latency_ms": {"p50": float(np.percentile(fm, 50)), "p99": float(np.percentile(fm, 99)), "max": float(max(fm))}}
+            r5["eng"].close()
+        if out is not None:
+            out["also"] = also
+    if out is not None:
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    job.close()
 
 
 if __name__ == "__main__":

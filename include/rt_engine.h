@@ -32,6 +32,10 @@ typedef struct rt_scene rt_scene;     /* host-side scene under construction / fl
 typedef struct rt_engine rt_engine;   /* one GPU: device copies of a scene, ray queues, frame buffer */
 
 const char* rt_last_error(void);
+/* A digest of the kernel sources this library was compiled from (first 16 hex digits of the sha256 of rt_engine.hip,
+ * rt_device.h and rt_flat.h, in that order; "unknown" for builds that do not pass it): profiles record it, so that a
+ * measurement can be tied to the code that ran. */
+const char* rt_source_hash(void);
 
 /* ---------------------------------------------------------------------------------------------------------
  * Quality settings: the QUALITY and PROGRAM blocks of Constants.h:4-17, made run-time values.
@@ -158,6 +162,20 @@ int rt_engine_sync(rt_engine* e);
 int rt_engine_poll(rt_engine* e);
 /* FrameManager::GetTexturePixelsToPresent (FrameManager.cpp:60-71): waits, then copies the engine's own frame buffer. */
 int rt_engine_read_frame(rt_engine* e, uint8_t* rgba_out);
+/* The same frame without a second copy: a pointer to the engine's own page-locked host buffer (width*height*4 bytes, same
+ * layout), valid until the next rt_engine_map_frame or rt_engine_destroy.  wait != 0: the complete frame, after everything
+ * queued has finished; the device-to-host copy runs on the render's stream right behind it.  wait == 0: the frame buffer
+ * as it stands while the render goes on (FrameManager.cpp:60-71 presents a frame in progress the same way): finished
+ * batches show their pixels, the rest what the buffer held before. */
+int rt_engine_map_frame(rt_engine* e, int wait, const uint8_t** rgba);
+/* memset(texturePixels, 0) of FrameManager::StartNewFrame (FrameManager.cpp:13) on the engine's own frame buffer, in
+ * stream order (NULL = the engine's stream). */
+int rt_engine_clear_frame(rt_engine* e, void* stream);
+/* FrameManager::TerminateAllThreads (FrameManager.cpp:31-38, state = Quit) without the wait: the render in flight (and
+ * only that one) stops taking rays; its remaining launches leave at once and batches that have not been resolved keep
+ * what the frame buffer held.  Returns immediately; rt_engine_sync then returns as soon as the rays in flight are done.
+ * A render started afterwards is not affected. */
+int rt_engine_cancel(rt_engine* e);
 /* Per-sample outputs (parity/debug).  rt_engine_keep_samples(e, 1) makes following renders record them; they can be read
  * after an rt_engine_render with n_ranks == 1 on a frame that fits one batch:
  * radiance[3] per sample, primary-hit object id (-1 = sky), primary HitInfo.distance, RNG draws.  Any pointer may be NULL.

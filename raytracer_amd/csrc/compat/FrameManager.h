@@ -2,7 +2,6 @@
 // end (App.h / App.cpp) compiles against it unchanged.  The seven worker threads are replaced by one asynchronous
 // rt_engine_render on the GPU.
 #pragma once
-#include <array>
 #include <chrono>
 #include <cstdint>
 
@@ -11,10 +10,11 @@
 class FrameManager {
 public:
     void StartNewFrame();               // FrameManager.cpp:7-30
-    void TerminateAllThreads();         // :31-38  — waits for the GPU
+    void TerminateAllThreads();         // :31-38  — cancels the render in flight and waits for the rays already on their way
     bool NeedUpdatingTexture();         // :40-48
     void FinishFrame();                 // :50-58  — prints "Frame calculating time" under LOG_BENCHMARK
-    void* GetTexturePixelsToPresent();  // :60-71  — W*H*4 bytes [A,B,G,R], row-major, top row first, pitch W*4
+    void* GetTexturePixelsToPresent();  // :60-71  — W*H*4 bytes [A,B,G,R], row-major, top row first, pitch W*4; page-locked
+                                        //            host memory owned by the engine; a frame in progress shows its finished part
     void ContinueWorkingOnImage();      // :73-76
     World& GetWorld() { return world; }
 
@@ -24,6 +24,4 @@ private:
     World world;
     std::chrono::system_clock::time_point frameStartTime;
     State state = State::Idle;
-    bool pixelsCurrent = false;
-    std::array<uint8_t, WINDOW_WIDTH * WINDOW_HEIGHT * 4> texturePixels{};
 };

@@ -75,20 +75,22 @@ glm::vec3 World::GetRayColor(const Ray& ray, int bounceAmount) {
 }
 
 void FrameManager::StartNewFrame() {
-    TerminateAllThreads();
+    TerminateAllThreads();                                    // FrameManager.cpp:9: the frame in flight is abandoned
     time += 1.0f;
     world.CreateWithNewTime(time);
-    memset(texturePixels.data(), 0, texturePixels.size());   // FrameManager.cpp:13
+    check(rt_engine_clear_frame(world.Engine(), nullptr), "rt_engine_clear_frame");   // FrameManager.cpp:13
     world.SyncCamera();
     world.frameSeed++;
     check(rt_engine_render(world.Engine(), world.frameSeed, 0, 1, nullptr, nullptr), "rt_engine_render");
     state = State::Rendering;
-    pixelsCurrent = false;
 #if LOG_BENCHMARK
     frameStartTime = std::chrono::system_clock::now();
 #endif
 }
+// FrameManager.cpp:31-38: state = Quit, wait for the workers to notice.  Here: the render in flight stops taking rays,
+// and the wait covers only the rays already on their way.
 void FrameManager::TerminateAllThreads() {
+    if (state == State::Rendering) check(rt_engine_cancel(world.Engine()), "rt_engine_cancel");
     check(rt_engine_sync(world.Engine()), "rt_engine_sync");
 }
 bool FrameManager::NeedUpdatingTexture() {
@@ -103,11 +105,13 @@ void FrameManager::FinishFrame() {
     std::cout << "Frame calculating time: " << dur.count() << std::endl;
 #endif
 }
+// FrameManager.cpp:60-71 pauses the workers and hands out the buffer they write into, finished or not.  Here the frame
+// buffer lives on the GPU; what is handed out is the engine's page-locked host copy of it: the complete frame once the
+// render has finished, a snapshot of the batches finished so far while it is still running (nothing is paused).
 void* FrameManager::GetTexturePixelsToPresent() {
-    if (!pixelsCurrent && state != State::Idle) {
-        check(rt_engine_read_frame(world.Engine(), texturePixels.data()), "rt_engine_read_frame");   // waits for the frame
-        pixelsCurrent = true;
-    }
-    return texturePixels.data();
+    const uint8_t* pixels = nullptr;
+    const int finished = state != State::Rendering || rt_engine_poll(world.Engine()) == 1;
+    check(rt_engine_map_frame(world.Engine(), finished, &pixels), "rt_engine_map_frame");
+    return const_cast<uint8_t*>(pixels);
 }
-void FrameManager::ContinueWorkingOnImage() {}
+void FrameManager::ContinueWorkingOnImage() {}   // FrameManager.cpp:73-76: nothing was paused

@@ -107,7 +107,14 @@ struct Batch {
     int wx0, wy0, ww, wh;            // render window inside the frame (the whole frame unless a test narrows it)
     uint32_t seed;
     FastDiv div_per_tile, div_tile_w, div_tiles_x;
+    // cancellation: the launches of one rt_engine_render carry its serial number; rt_engine_cancel stores the serial of
+    // the render in flight in *cancel, and kernels that find their own serial there stop taking work
+    const uint32_t* cancel;
+    uint32_t serial;
 };
+__device__ __forceinline__ bool cancelled(const Batch& bt) {
+    return __hip_atomic_load(bt.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == bt.serial;
+}
 struct Queues {
     float4* a[2]; float4* b[2];      // ray records: a = (o.xyz, d.x), b = (d.y, d.z, slot, ctr | depth << 24)
     float4* hit;                     // hit records by queue position: (distance, best entry, u, v)
@@ -222,7 +229,7 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
     const uint32_t n_in = FIRST ? (uint32_t)bt.n_pixels * (uint32_t)(g.S * g.S) : q.counts[pass];
     // a pass with few rays: blocks beyond one smallest reservation per wave leave before they copy the scene
     const uint32_t blocks_used = min((uint32_t)gridDim.x, n_in / ((uint32_t)tune.min_chunk * (IBLOCK / 64)) + 1u);
-    if (n_in == 0u || blockIdx.x >= blocks_used) return;
+    if (n_in == 0u || blockIdx.x >= blocks_used || cancelled(bt)) return;
     const Store st = stage_scene<STAGED>(sc, smem);
     const int qin = (pass + 1) & 1;
     // Range r of the queue is every NCUR-th stripe of STRIPE positions, starting with stripe r: all ranges move through
@@ -256,8 +263,10 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
                     const uint32_t size = range_size(n_stripes, range);
                     uint32_t off = 0xFFFFFFFFu;
                     if (size) {
-                        if (lane == 0) off = atomicAdd(q.cursors + range * CUR_STRIDE + pass, chunk);
+                        // a cancelled frame hands out no more rays: the wave finishes the ones it holds and leaves
+                        if (lane == 0) off = cancelled(bt) ? 0xFFFFFFFFu : atomicAdd(q.cursors + range * CUR_STRIDE + pass, chunk);
                         off = (uint32_t)__shfl((int)off, 0);
+                        if (off == 0xFFFFFFFFu) break;
                     }
                     if (off < size) {
                         mine = off;
@@ -382,6 +391,7 @@ __global__ __launch_bounds__(256) void shade_kernel(Scene sc, Cam cam, Cfg g, Ba
     const uint32_t n_in = FIRST ? (uint32_t)bt.n_pixels * (uint32_t)(g.S * g.S) : q.counts[pass];
     const uint32_t n_tiles = (n_in + STILE - 1) / STILE;
     for (uint32_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+      if (cancelled(bt)) return;      // one address for the whole block: every thread takes the same way
       if (threadIdx.x == 0) s_count = 0;
       __syncthreads();
       for (uint32_t k = 0; k < STILE / 256; k++) {
@@ -436,6 +446,7 @@ constexpr int RTILE = 2048;   // float4 records staged per block and step (32 Ki
 __device__ __forceinline__ uint32_t to_u8(float c) { return (uint32_t)(int)(c * 255) & 0xFFu; }
 __global__ __launch_bounds__(256) void resolve_kernel(Cfg g, Batch bt, const float4* radiance, uint8_t* out, int packed, int rpb, int rch, FastDiv div_rch) {
     __shared__ float4 tile[RTILE + 256];
+    if (cancelled(bt)) return;        // the pixels of a cancelled batch keep what the frame buffer held
     const int spp = g.S * g.S;
     const int p0 = blockIdx.x * rpb;                                   // first pixel of the block
     const int n_p = min(rpb, bt.n_pixels - p0);
@@ -602,6 +613,13 @@ struct rt_engine {
     hipStream_t stream = nullptr;
     hipStream_t last_stream = nullptr;  // the stream of the latest render / assemble when the caller brought its own
     unsigned char* d_scratch = nullptr; // this device's copy of the static staging array (rt_engine_trace_static)
+    // cancellation and presentation
+    hipStream_t side_stream = nullptr;  // carries the cancel word and frame snapshots past a render that is still running
+    uint32_t* d_cancel = nullptr;       // serial of the cancelled render (kernels compare it with their own)
+    uint32_t* h_serial = nullptr;       // pinned: source of the copy into d_cancel
+    uint32_t serial = 0;                // serial of the latest render / ray query
+    uint8_t* h_frame = nullptr;         // pinned host copy of the frame (rt_engine_map_frame), allocated on first use
+    bool frame_dirty = false;           // the frame buffer changed since the last complete copy into h_frame
     Scene sc{};
     bool have_scene = false, have_camera = false;
     Cam cam{};
@@ -666,6 +684,7 @@ Batch make_batch(const rt_engine* e, int rank, int n_ranks, uint32_t seed) {
     b.wx0 = e->win[0]; b.wy0 = e->win[1]; b.ww = e->win[2]; b.wh = e->win[3];
     b.div_per_tile = make_fastdiv((uint32_t)(c.tile_w * c.tile_h)); b.div_tile_w = make_fastdiv((uint32_t)c.tile_w);
     b.div_tiles_x = make_fastdiv((uint32_t)b.tiles_x);
+    b.cancel = e->d_cancel; b.serial = e->serial;
     return b;
 }
 
@@ -731,6 +750,11 @@ int wait_all(rt_engine* e) {
 
 extern "C" {
 
+#ifndef RT_SOURCE_HASH
+#define RT_SOURCE_HASH "unknown"
+#endif
+const char* rt_source_hash(void) { return RT_SOURCE_HASH; }
+
 int rt_engine_create(const rt_config* cfg, rt_engine** out) {
     if (!cfg || !out) return fail(RT_E_INVALID, "null argument");
     if (cfg->width <= 0 || cfg->height <= 0 || cfg->samples_per_axis <= 0 || cfg->bounces < 0 || cfg->bounces > 32)
@@ -771,6 +795,10 @@ int init_engine(rt_engine* e, const rt_config* cfg) {
     HIP_TRY(hipGetDeviceProperties(&prop, cfg->device));
     e->n_cus = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreate(&e->stream));
+    HIP_TRY(hipStreamCreateWithFlags(&e->side_stream, hipStreamNonBlocking));
+    HIP_TRY(hipMalloc((void**)&e->d_cancel, 256));
+    HIP_TRY(hipMemset(e->d_cancel, 0, 256));
+    HIP_TRY(hipHostMalloc((void**)&e->h_serial, 256, hipHostMallocDefault));
     // the engine's device is current (rt_engine_create): the address of this GPU's copy of the staging array
     HIP_TRY(hipGetSymbolAddress((void**)&e->d_scratch, HIP_SYMBOL(scratch)));
     const size_t cap = (size_t)e->q.capacity;
@@ -823,6 +851,10 @@ void rt_engine_destroy(rt_engine* e) {
     (void)hipFree(e->q.stack); (void)hipFree(e->q.radiance); (void)hipFree(e->d_frame); (void)hipFree(e->d_counts_all);
     (void)hipFree(e->dbg.primary_id); (void)hipFree(e->dbg.primary_t); (void)hipFree(e->dbg.rng_draws);
     for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
+    if (e->side_stream) { (void)hipStreamSynchronize(e->side_stream); (void)hipStreamDestroy(e->side_stream); }
+    (void)hipFree(e->d_cancel);
+    if (e->h_serial) (void)hipHostFree(e->h_serial);
+    if (e->h_frame) (void)hipHostFree(e->h_frame);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -997,6 +1029,8 @@ int rt_engine_render(rt_engine* e, uint32_t seed, int rank, int n_ranks, uint8_t
     if (n_ranks > 1) HIP_TRY(hipMemsetAsync(out, 0, (size_t)my_pixels * 4, st));
     e->ev_used = 0;
     e->last_batches = n_batches;
+    e->serial = e->serial + 1u ? e->serial + 1u : 1u;   // never 0: the cancel word starts as 0
+    if (out == e->d_frame) e->frame_dirty = true;
     {   // samples of the pixels this rank owns
         uint64_t px = 0;
         const int n_tiles = tiles_x(e) * tiles_y(e);
@@ -1062,6 +1096,53 @@ int rt_engine_read_frame(rt_engine* e, uint8_t* rgba_out) {
     HIP_TRY(hipSetDevice(e->cfg.device));
     if (int rc = wait_all(e)) return rc;
     HIP_TRY(hipMemcpy(rgba_out, e->d_frame, (size_t)e->cfg.width * e->cfg.height * 4, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+// FrameManager::TerminateAllThreads without the wait (FrameManager.cpp:31-38: state = Quit): the render in flight stops
+// taking rays and its remaining launches leave at once.  The store travels on a stream of its own, so it overtakes the
+// render; a render queued later carries another serial and is not affected, whichever reaches the GPU first.
+int rt_engine_cancel(rt_engine* e) {
+    if (!e) return fail(RT_E_INVALID, "null engine");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    HIP_TRY(hipStreamSynchronize(e->side_stream));      // the pinned source word is free again
+    *e->h_serial = e->serial;
+    HIP_TRY(hipMemcpyAsync(e->d_cancel, e->h_serial, 4, hipMemcpyHostToDevice, e->side_stream));
+    return RT_OK;
+}
+// memset(texturePixels, 0) of FrameManager::StartNewFrame (FrameManager.cpp:13), in stream order
+int rt_engine_clear_frame(rt_engine* e, void* stream) {
+    if (!e) return fail(RT_E_INVALID, "null engine");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    hipStream_t st = stream ? (hipStream_t)stream : e->stream;
+    e->last_stream = stream ? (hipStream_t)stream : nullptr;
+    HIP_TRY(hipMemsetAsync(e->d_frame, 0, (size_t)e->cfg.width * e->cfg.height * 4, st));
+    e->frame_dirty = true;
+    return RT_OK;
+}
+// FrameManager::GetTexturePixelsToPresent (FrameManager.cpp:60-71) without a second copy: the engine's frame buffer in
+// page-locked host memory.  wait != 0: after everything queued has finished (the complete frame).  wait == 0: as the
+// frame buffer stands now, while the render goes on — batches that have finished show their pixels, the rest what the
+// buffer held before (zero after rt_engine_clear_frame), which is how the reference presents a frame in progress.
+int rt_engine_map_frame(rt_engine* e, int wait, const uint8_t** rgba) {
+    if (!e || !rgba) return fail(RT_E_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    const size_t bytes = (size_t)e->cfg.width * e->cfg.height * 4;
+    if (!e->h_frame) HIP_TRY(hipHostMalloc((void**)&e->h_frame, bytes, hipHostMallocDefault));
+    if (wait) {
+        if (e->frame_dirty) {
+            // on the stream that carries the render, right behind it
+            hipStream_t st = e->last_stream ? e->last_stream : e->stream;
+            HIP_TRY(hipStreamSynchronize(e->side_stream));          // a snapshot may still be writing the same host buffer
+            HIP_TRY(hipMemcpyAsync(e->h_frame, e->d_frame, bytes, hipMemcpyDeviceToHost, st));
+            if (int rc = wait_all(e)) return rc;
+            e->frame_dirty = false;
+        }
+    } else {
+        HIP_TRY(hipMemcpyAsync(e->h_frame, e->d_frame, bytes, hipMemcpyDeviceToHost, e->side_stream));
+        HIP_TRY(hipStreamSynchronize(e->side_stream));
+    }
+    *rgba = e->h_frame;
     return RT_OK;
 }
 
@@ -1191,6 +1272,7 @@ static int rt_engine_ray_color_impl(rt_engine* e, int n, const float* o3, const 
             (void)hipMemsetAsync(d_counts, 0, sizeof(uint32_t) * words, e->stream);
             // the rays enter pass 0 through queue (0+1)&1 = 1
             hipLaunchKernelGGL(load_rays_kernel, dim3((n + 255) / 256), dim3(256), 0, e->stream, n, d_o, d_d, e->q.a[1], e->q.b[1], d_counts);
+            e->serial = e->serial + 1u ? e->serial + 1u : 1u;
             const Debug saved = e->dbg;
             const bool saved_timing = e->time_kernels;
             e->dbg = Debug{nullptr, nullptr, nullptr, d_keys, e->dbg.prof};

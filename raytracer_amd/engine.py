@@ -46,6 +46,7 @@ _V = C.c_void_p
 _PV = C.POINTER(C.c_void_p)
 SIGNATURES = {
     "rt_last_error": (C.c_char_p, []),
+    "rt_source_hash": (C.c_char_p, []),
     "rt_config_defaults": (None, [C.POINTER(Config)]),
     "rt_scene_create": (C.c_int, [_PV]),
     "rt_scene_destroy": (None, [_V]),
@@ -87,6 +88,9 @@ SIGNATURES = {
     "rt_engine_sync": (C.c_int, [_V]),
     "rt_engine_poll": (C.c_int, [_V]),
     "rt_engine_read_frame": (C.c_int, [_V, u8p]),
+    "rt_engine_map_frame": (C.c_int, [_V, C.c_int, _PV]),
+    "rt_engine_clear_frame": (C.c_int, [_V, _V]),
+    "rt_engine_cancel": (C.c_int, [_V]),
     "rt_engine_keep_samples": (C.c_int, [_V, C.c_int]),
     "rt_engine_read_samples": (C.c_int, [_V, _V, _V, _V, _V]),
     "rt_engine_trace": (C.c_int, [_V, C.c_int, f32p, f32p, i32p, f32p]),
@@ -124,6 +128,11 @@ def lib():
         fn.argtypes = args
     _L = L
     return L
+
+
+def source_hash():
+    """digest of the kernel sources the loaded library was compiled from"""
+    return lib().rt_source_hash().decode()
 
 
 def _check(rc):
@@ -364,6 +373,24 @@ class Engine:
     def render_frame(self, seed):
         self.render(seed)
         return self.read_frame()
+
+    def map_frame(self, wait=True):
+        """The frame in the engine's page-locked host buffer, as a read-only view (no copy); valid until the next call.
+        wait=False: a snapshot of the frame buffer while the render goes on."""
+        p = C.c_void_p()
+        _check(self.L.rt_engine_map_frame(self.h, int(wait), C.byref(p)))
+        n = self.cfg.height * self.cfg.width * 4
+        buf = (C.c_uint8 * n).from_address(p.value)
+        a = np.frombuffer(buf, np.uint8).reshape(self.cfg.height, self.cfg.width, 4)
+        a.flags.writeable = False
+        return a
+
+    def clear_frame(self, stream=None):
+        _check(self.L.rt_engine_clear_frame(self.h, stream))
+
+    def cancel(self):
+        """The render in flight stops taking rays (returns at once; sync() then returns early)."""
+        _check(self.L.rt_engine_cancel(self.h))
 
     def keep_samples(self, enable=True):
         _check(self.L.rt_engine_keep_samples(self.h, int(enable)))

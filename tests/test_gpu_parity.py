@@ -359,6 +359,50 @@ def test_error_behaviour(rt, gpu_default):
     assert E.lib().rt_last_error()
 
 
+def test_cancel_and_host_frame(rt, gpu_default):
+    """FrameManager's Quit and presentation handshakes (FrameManager.cpp:31-38, 60-76) on the GPU: a render in flight can
+    be abandoned without waiting for it, the next frame is untouched by that, and the page-locked host frame holds the
+    bytes of the device frame — the whole frame after the render, its finished batches while the render goes on."""
+    import time
+    W, H, S, B = 1920, 1080, 16, 8          # 256 spp in 16 batches of 2^25 paths: about a hundred milliseconds
+    e = make_engine(rt, gpu_default, W, H, S, B, max_batch_paths=1 << 25)
+    e.render(21)
+    e.sync()
+    t0 = time.perf_counter()
+    e.render(21)
+    e.sync()
+    t_full = time.perf_counter() - t0
+    want = e.read_frame()
+    assert_bits(e.map_frame(wait=True), want, "page-locked frame vs read_frame")
+    assert want.any()
+    # abandon a frame after a third of its time
+    e.clear_frame()
+    t0 = time.perf_counter()
+    e.render(22)
+    time.sleep(0.33 * t_full)
+    snap = e.map_frame(wait=False).copy()      # while the render goes on
+    e.cancel()
+    e.sync()
+    t_cancelled = time.perf_counter() - t0
+    assert t_cancelled < 0.75 * t_full, f"a cancelled frame took {t_cancelled * 1e3:.0f} ms of {t_full * 1e3:.0f} ms"
+    part = e.map_frame(wait=True).copy()
+    done = part[..., 0] == 255                 # alpha is 255 in every rendered pixel, 0 in a cleared one
+    assert 0 < done.mean() < 1, f"a cancelled frame should be partly rendered, {done.mean():.3f} is"
+    assert (snap[..., 0] == 255).mean() <= done.mean()
+    # the next frame does not know about it
+    e.render(21)
+    assert_bits(e.map_frame(wait=True), want, "frame after a cancelled one")
+    # cancelling with nothing in flight, and a cancel that arrives after its frame has finished, change nothing
+    e.cancel()
+    e.render(21)
+    e.sync()
+    e.cancel()
+    assert_bits(e.read_frame(), want, "frame after stray cancels")
+    st = e.stats()
+    assert st["paths"] == W * H * S * S
+    print(f"full frame {t_full * 1e3:.0f} ms, cancelled after {0.33 * t_full * 1e3:.0f} ms: back in {t_cancelled * 1e3:.0f} ms, {done.mean():.2f} of the pixels done")
+
+
 def test_front_end_adapter_matches_the_c_abi(rt, gpu_default, tmp_path):
     """raytracer_amd/compat_demo drives the FrameManager / World / Camera adapter (raytracer_amd/csrc/compat, the
     reference's class interface over the C ABI) like the reference's main loop, at the resolution and quality of the

@@ -16,7 +16,21 @@ def short(name):
     return (m.group(1) + (m.group(2) or "")) if m else name[:60]
 
 
+def source_hash():
+    """digest of the kernel sources the profiled library was compiled from (rt_source_hash of librt_engine.so)"""
+    import ctypes
+    import os
+    lib = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "raytracer_amd", "librt_engine.so")
+    try:
+        L = ctypes.CDLL(lib)
+        L.rt_source_hash.restype = ctypes.c_char_p
+        return L.rt_source_hash().decode()
+    except (OSError, AttributeError):
+        return "unknown"
+
+
 def main():
+    print(f"source_hash: {source_hash()}")
     tot = collections.defaultdict(lambda: collections.defaultdict(float))
     calls = collections.defaultdict(set)
     for d in sys.argv[1:]:

@@ -8,7 +8,7 @@ TAG=${1:-prof}; shift || true
 OUT=$R/gpurun_out/$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 2 --warmup 1 --no-cpu-baseline $*"
+ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-also $*"
 
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 $R/bench.py $ARGS > $OUT/bench.json 2> $OUT/trace.log || { echo "kernel trace run failed"; tail -5 $OUT/trace.log; exit 1; }
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
@@ -39,7 +39,7 @@ P5="GRBM_GUI_ACTIVE SQ_WAVES SQ_LEVEL_WAVES"
 i=0
 for P in "$P1" "$P2" "$P3" "$P4" "$P5"; do
     i=$((i + 1))
-    timeout -s KILL 120 rocprofv3 --pmc $P --output-format csv -d $OUT/pmc$i -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline $* > $OUT/pmc$i.log 2>&1 || { echo "pmc pass $i failed"; tail -3 $OUT/pmc$i.log; exit 1; }
+    timeout -s KILL 120 rocprofv3 --pmc $P --output-format csv -d $OUT/pmc$i -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-also $* > $OUT/pmc$i.log 2>&1 || { echo "pmc pass $i failed"; tail -3 $OUT/pmc$i.log; exit 1; }
 done
 python3 $R/tools/pmc_summary.py $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc4 $OUT/pmc5 > $OUT/pmc_summary.txt
 rm -rf $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 $OUT/pmc4 $OUT/pmc5 $OUT/pmc*.log $OUT/trace.log
