@@ -217,6 +217,28 @@ int rt_engine_eval_rng(rt_engine* e, int n, const uint32_t* key, const uint32_t*
 int rt_engine_check_division(rt_engine* e, int n, const float* a, const float* b, uint32_t seed, int threads, int rounds,
                              uint64_t* mismatches, float* first_bad4);
 
+/* ---------------------------------------------------------------------------------------------------------
+ * Several GPUs behind one handle, in one process — for a front end that owns one FrameManager (App.h:27) and should use
+ * a whole node: FrameManager.cpp:17-21 splits the frame over THREAD_COUNT threads, this splits it over n_dev devices.
+ * The scene is replicated; device k renders tiles k, k+n, ...; the first device of the list gathers the others' tiles
+ * with peer-to-peer copies and holds the frame.  All calls queue work and return, except sync and map_frame(wait).
+ * A device may be listed more than once.  rt_multi_engine(m, k) gives engine k (statistics, queries); engine 0 is the
+ * display engine, whose own frame buffer receives the frame.
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct rt_multi rt_multi;
+int rt_multi_create(const rt_config* cfg, const int32_t* device_ids, int n_dev, rt_multi** out);   /* cfg->device is ignored */
+void rt_multi_destroy(rt_multi* m);
+int rt_multi_count(const rt_multi* m);
+rt_engine* rt_multi_engine(rt_multi* m, int k);
+int rt_multi_set_scene(rt_multi* m, const rt_scene* s);
+int rt_multi_set_camera(rt_multi* m, const float cam12[12]);
+int rt_multi_render(rt_multi* m, uint32_t frame_seed);               /* FrameManager::StartNewFrame, FrameManager.cpp:7-30 */
+int rt_multi_poll(rt_multi* m);                                      /* FrameManager::NeedUpdatingTexture, :40-48 */
+int rt_multi_sync(rt_multi* m);
+int rt_multi_cancel(rt_multi* m);                                    /* FrameManager::TerminateAllThreads, :31-38 */
+int rt_multi_clear_frame(rt_multi* m);                               /* FrameManager.cpp:13 */
+int rt_multi_map_frame(rt_multi* m, int wait, const uint8_t** rgba); /* FrameManager::GetTexturePixelsToPresent, :60-71 */
+
 #ifdef __cplusplus
 }
 #endif

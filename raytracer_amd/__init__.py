@@ -4,4 +4,4 @@
 HIP engine.  `raytracer_amd.distributed` splits a frame across the GPUs of a node by image tiles.
 """
 from . import engine  # noqa: F401
-from .engine import Config, Engine, RtError, Scene, alt_scene, camera_input, camera_look, default_config, default_scene  # noqa: F401
+from .engine import Config, Engine, MultiEngine, RtError, Scene, alt_scene, camera_input, camera_look, default_config, default_scene  # noqa: F401

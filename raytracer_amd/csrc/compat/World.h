@@ -1,5 +1,7 @@
 // Adapter header with the reference's name (World.h:12-32): the scene and camera owner the front end reaches through
-// FrameManager::GetWorld().  The scene lives in an rt_scene, the pixels come from an rt_engine.
+// FrameManager::GetWorld().  The scene lives in an rt_scene, the pixels come from an rt_multi: one engine per GPU named in
+// RT_DEVICES (a comma-separated list of HIP device ordinals; default: RT_DEVICE, else device 0), the first being the one
+// that holds the frame.
 #pragma once
 #include <string>
 
@@ -21,7 +23,8 @@ public:
     Camera& GetWorldCamera() { return camera; }
 
     // adapter internals used by FrameManager
-    rt_engine* Engine() { return engine; }
+    rt_multi* Devices() { return devices; }
+    rt_engine* Engine() { return rt_multi_engine(devices, 0); }   // the display engine: single-pixel and single-ray queries
     void SyncCamera();
     uint32_t frameSeed = 1;      // keys the per-(pixel, sample) RNG streams of the next frame
     uint32_t buildKey = 1;       // keys the BVH axis choices (the reference draws them from std::rand, Object.cpp:191)
@@ -29,6 +32,6 @@ public:
 private:
     void BuildScene(float time);
     rt_scene* scene = nullptr;
-    rt_engine* engine = nullptr;
+    rt_multi* devices = nullptr;
     Camera camera;
 };

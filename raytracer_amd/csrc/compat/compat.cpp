@@ -27,12 +27,22 @@ World::World(float time) : camera({glm::vec3{0, 3, -10}, glm::vec3{0, 0, 1}}) { 
     cfg.samples_per_axis = SAMPLES_PER_PIXEL_AXIS; cfg.bounces = LIGHT_BOUNCE_AMOUNT;
     cfg.fov = FIELD_OF_VIEW; cfg.skybox_brightness = SKYBOX_BRIGHTNESS;
     cfg.dof_intensity = DEPTH_OF_FIELD_INTENSITY; cfg.focus_distance = FOCUS_DISTANCE;
-    if (const char* d = getenv("RT_DEVICE")) cfg.device = atoi(d);
-    check(rt_engine_create(&cfg, &engine), "rt_engine_create");
+    std::vector<int32_t> ids;
+    if (const char* list = getenv("RT_DEVICES")) {
+        for (const char* p = list; *p;) {
+            char* end = nullptr;
+            const long v = strtol(p, &end, 10);
+            if (end == p) break;
+            ids.push_back((int32_t)v);
+            p = (*end == ',') ? end + 1 : end;
+        }
+    }
+    if (ids.empty()) ids.push_back(getenv("RT_DEVICE") ? atoi(getenv("RT_DEVICE")) : 0);
+    check(rt_multi_create(&cfg, ids.data(), (int)ids.size(), &devices), "rt_multi_create");
     BuildScene(time);
 }
 World::~World() {
-    rt_engine_destroy(engine);
+    rt_multi_destroy(devices);
     rt_scene_destroy(scene);
 }
 void World::BuildScene(float time) {
@@ -42,7 +52,7 @@ void World::BuildScene(float time) {
     int rc = rt_scene_add_default_objects(fresh, root ? root : ".", time);
     if (rc >= 0) rc = rt_scene_build(fresh, buildKey);
     if (rc < 0) { rt_scene_destroy(fresh); check(rc, "scene"); }
-    check(rt_engine_set_scene(engine, fresh), "rt_engine_set_scene");
+    check(rt_multi_set_scene(devices, fresh), "rt_multi_set_scene");
     rt_scene_destroy(scene);
     scene = fresh;
 }
@@ -53,10 +63,11 @@ void World::CreateWithNewTime(float) {}
 void World::SyncCamera() {
     float cam[12];
     camera.Pack(cam);
-    check(rt_engine_set_camera(engine, cam), "rt_engine_set_camera");
+    check(rt_multi_set_camera(devices, cam), "rt_multi_set_camera");
 }
 glm::u8vec3 World::CalculateColorForScreenPosition(int x, int y) {
     SyncCamera();
+    rt_engine* engine = Engine();
     check(rt_engine_set_window(engine, x, y, x + 1, y + 1), "rt_engine_set_window");
     check(rt_engine_render(engine, frameSeed, 0, 1, nullptr, nullptr), "rt_engine_render");
     static thread_local std::vector<uint8_t> frame;
@@ -70,7 +81,7 @@ glm::vec3 World::GetRayColor(const Ray& ray, int bounceAmount) {
     const float o[3] = {ray.pos.x, ray.pos.y, ray.pos.z}, d[3] = {ray.direction.x, ray.direction.y, ray.direction.z};
     const uint32_t key = frameSeed;
     float rgb[3];
-    check(rt_engine_ray_color(engine, 1, o, d, bounceAmount, &key, rgb), "rt_engine_ray_color");
+    check(rt_engine_ray_color(Engine(), 1, o, d, bounceAmount, &key, rgb), "rt_engine_ray_color");
     return {rgb[0], rgb[1], rgb[2]};
 }
 
@@ -78,10 +89,10 @@ void FrameManager::StartNewFrame() {
     TerminateAllThreads();                                    // FrameManager.cpp:9: the frame in flight is abandoned
     time += 1.0f;
     world.CreateWithNewTime(time);
-    check(rt_engine_clear_frame(world.Engine(), nullptr), "rt_engine_clear_frame");   // FrameManager.cpp:13
+    check(rt_multi_clear_frame(world.Devices()), "rt_multi_clear_frame");   // FrameManager.cpp:13
     world.SyncCamera();
     world.frameSeed++;
-    check(rt_engine_render(world.Engine(), world.frameSeed, 0, 1, nullptr, nullptr), "rt_engine_render");
+    check(rt_multi_render(world.Devices(), world.frameSeed), "rt_multi_render");
     state = State::Rendering;
 #if LOG_BENCHMARK
     frameStartTime = std::chrono::system_clock::now();
@@ -90,12 +101,12 @@ void FrameManager::StartNewFrame() {
 // FrameManager.cpp:31-38: state = Quit, wait for the workers to notice.  Here: the render in flight stops taking rays,
 // and the wait covers only the rays already on their way.
 void FrameManager::TerminateAllThreads() {
-    if (state == State::Rendering) check(rt_engine_cancel(world.Engine()), "rt_engine_cancel");
-    check(rt_engine_sync(world.Engine()), "rt_engine_sync");
+    if (state == State::Rendering) check(rt_multi_cancel(world.Devices()), "rt_multi_cancel");
+    check(rt_multi_sync(world.Devices()), "rt_multi_sync");
 }
 bool FrameManager::NeedUpdatingTexture() {
     if (state == State::AllComplete || state == State::Idle) return false;
-    if (rt_engine_poll(world.Engine()) == 1) FinishFrame();
+    if (rt_multi_poll(world.Devices()) == 1) FinishFrame();
     return true;
 }
 void FrameManager::FinishFrame() {
@@ -110,8 +121,8 @@ void FrameManager::FinishFrame() {
 // render has finished, a snapshot of the batches finished so far while it is still running (nothing is paused).
 void* FrameManager::GetTexturePixelsToPresent() {
     const uint8_t* pixels = nullptr;
-    const int finished = state != State::Rendering || rt_engine_poll(world.Engine()) == 1;
-    check(rt_engine_map_frame(world.Engine(), finished, &pixels), "rt_engine_map_frame");
+    const int finished = state != State::Rendering || rt_multi_poll(world.Devices()) == 1;
+    check(rt_multi_map_frame(world.Devices(), finished, &pixels), "rt_multi_map_frame");
     return const_cast<uint8_t*>(pixels);
 }
 void FrameManager::ContinueWorkingOnImage() {}   // FrameManager.cpp:73-76: nothing was paused

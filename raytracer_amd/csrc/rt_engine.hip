@@ -1064,6 +1064,7 @@ int rt_engine_assemble(rt_engine* e, const uint8_t* d_gathered, int n_ranks, uin
     hipStream_t st = stream ? (hipStream_t)stream : e->stream;
     e->last_stream = stream ? (hipStream_t)stream : nullptr;
     uint8_t* out = d_rgba ? d_rgba : e->d_frame;
+    if (out == e->d_frame) e->frame_dirty = true;
     const long long per_rank = rt_engine_tile_bytes(e, n_ranks) / 4;
     const long long total = per_rank * n_ranks;
     Batch bt = make_batch(e, 0, n_ranks, 0);
@@ -1405,6 +1406,127 @@ int rt_engine_check_division(rt_engine* e, int n, const float* a, const float* b
     HIP_TRY(hipMemcpy(first_bad4, dbad.p, 16, hipMemcpyDeviceToHost));
     *mismatches = m[0];
     return RT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Several GPUs behind one handle, in one process: what a front end that owns a single FrameManager needs in order to use
+// a whole node.  The scene is replicated; device k renders tiles k, k+n, ... into a packed buffer of its own; the display
+// device (the first of the list) waits for each peer's event, pulls the peer's buffer over with one peer-to-peer copy and
+// scatters all tiles into its frame buffer.  No host thread per device: everything is queued from the caller's thread,
+// asynchronously.  A device may be listed more than once (each entry gets an engine of its own), which is how a one-GPU
+// machine exercises the same code.
+struct rt_multi {
+    std::vector<rt_engine*> eng;
+    std::vector<uint8_t*> d_tiles;      // per engine, on its device: rt_engine_tile_bytes
+    std::vector<hipEvent_t> done;       // per engine: its tiles are complete
+    uint8_t* d_gathered = nullptr;      // on the display device: n packed buffers back to back
+    size_t tile_bytes = 0;
+};
+
+void rt_multi_destroy(rt_multi* m) {
+    if (!m) return;
+    for (size_t k = 0; k < m->eng.size(); k++) {
+        if (!m->eng[k]) continue;
+        (void)hipSetDevice(m->eng[k]->cfg.device);
+        (void)wait_all(m->eng[k]);
+        if (k < m->d_tiles.size()) (void)hipFree(m->d_tiles[k]);
+        if (k < m->done.size() && m->done[k]) (void)hipEventDestroy(m->done[k]);
+    }
+    if (!m->eng.empty() && m->eng[0]) { (void)hipSetDevice(m->eng[0]->cfg.device); (void)hipFree(m->d_gathered); }
+    for (rt_engine* e : m->eng) rt_engine_destroy(e);
+    delete m;
+}
+
+int rt_multi_create(const rt_config* cfg, const int32_t* device_ids, int n_dev, rt_multi** out) {
+    if (!cfg || !device_ids || !out || n_dev <= 0 || n_dev > 64) return fail(RT_E_INVALID, "rt_multi_create: 1 to 64 devices");
+    return rt::guard([&] {
+        rt_multi* m = new rt_multi();
+        m->eng.assign((size_t)n_dev, nullptr);
+        m->d_tiles.assign((size_t)n_dev, nullptr);
+        m->done.assign((size_t)n_dev, nullptr);
+        for (int k = 0; k < n_dev; k++) {
+            rt_config c = *cfg;
+            c.device = device_ids[k];
+            // an engine's queues hold its own share of the frame at most
+            {
+                const int tw = c.tile_w > 0 ? c.tile_w : 64, th = c.tile_h > 0 ? c.tile_h : 64;
+                const long long tiles = (long long)((c.width + tw - 1) / tw) * ((c.height + th - 1) / th);
+                const long long share = ((tiles + n_dev - 1) / n_dev) * tw * th * (long long)c.samples_per_axis * c.samples_per_axis;
+                const long long cap = c.max_batch_paths > 0 ? c.max_batch_paths : (1ll << 27);
+                c.max_batch_paths = (int)std::min(cap, share);
+            }
+            if (int rc = rt_engine_create(&c, &m->eng[k])) { rt_multi_destroy(m); return rc; }
+            hipError_t he = hipEventCreateWithFlags(&m->done[k], hipEventDisableTiming);
+            if (he == hipSuccess && n_dev > 1) {
+                m->tile_bytes = (size_t)rt_engine_tile_bytes(m->eng[k], n_dev);
+                he = hipMalloc((void**)&m->d_tiles[k], m->tile_bytes);
+            }
+            if (he != hipSuccess) { rt_multi_destroy(m); return fail(RT_E_DEVICE, hipGetErrorString(he)); }
+        }
+        if (n_dev > 1) {
+            (void)hipSetDevice(m->eng[0]->cfg.device);
+            if (hipMalloc((void**)&m->d_gathered, m->tile_bytes * (size_t)n_dev) != hipSuccess) { rt_multi_destroy(m); return fail(RT_E_NOMEM, "device allocation failed"); }
+            for (int k = 1; k < n_dev; k++)   // direct access to the peers' buffers where the devices differ (xGMI); ignored if already on
+                if (m->eng[k]->cfg.device != m->eng[0]->cfg.device) (void)hipDeviceEnablePeerAccess(m->eng[k]->cfg.device, 0);
+            (void)hipGetLastError();
+        }
+        *out = m;
+        return RT_OK;
+    });
+}
+int rt_multi_count(const rt_multi* m) { return m ? (int)m->eng.size() : 0; }
+rt_engine* rt_multi_engine(rt_multi* m, int k) { return (m && k >= 0 && k < (int)m->eng.size()) ? m->eng[k] : nullptr; }
+int rt_multi_set_scene(rt_multi* m, const rt_scene* s) {
+    if (!m) return fail(RT_E_INVALID, "null handle");
+    for (rt_engine* e : m->eng) if (int rc = rt_engine_set_scene(e, s)) return rc;
+    return RT_OK;
+}
+int rt_multi_set_camera(rt_multi* m, const float cam12[12]) {
+    if (!m) return fail(RT_E_INVALID, "null handle");
+    for (rt_engine* e : m->eng) if (int rc = rt_engine_set_camera(e, cam12)) return rc;
+    return RT_OK;
+}
+// One frame into the display engine's own frame buffer (rt_multi_map_frame / rt_engine_read_frame on engine 0 hand it out).
+int rt_multi_render(rt_multi* m, uint32_t frame_seed) {
+    if (!m) return fail(RT_E_INVALID, "null handle");
+    const int n = (int)m->eng.size();
+    if (n == 1) return rt_engine_render(m->eng[0], frame_seed, 0, 1, nullptr, nullptr);
+    for (int k = 0; k < n; k++) {
+        rt_engine* e = m->eng[k];
+        if (int rc = rt_engine_render(e, frame_seed, k, n, m->d_tiles[k], nullptr)) return rc;
+        HIP_TRY(hipEventRecord(m->done[k], e->stream));     // the engine's device is current after rt_engine_render
+    }
+    rt_engine* d = m->eng[0];
+    HIP_TRY(hipSetDevice(d->cfg.device));
+    for (int k = 0; k < n; k++) {
+        rt_engine* e = m->eng[k];
+        if (k > 0) HIP_TRY(hipStreamWaitEvent(d->stream, m->done[k], 0));
+        uint8_t* dst = m->d_gathered + (size_t)k * m->tile_bytes;
+        if (e->cfg.device == d->cfg.device) HIP_TRY(hipMemcpyAsync(dst, m->d_tiles[k], m->tile_bytes, hipMemcpyDeviceToDevice, d->stream));
+        else HIP_TRY(hipMemcpyPeerAsync(dst, d->cfg.device, m->d_tiles[k], e->cfg.device, m->tile_bytes, d->stream));
+    }
+    return rt_engine_assemble(d, m->d_gathered, n, nullptr, nullptr);
+}
+int rt_multi_poll(rt_multi* m) {
+    if (!m) return fail(RT_E_INVALID, "null handle");
+    for (rt_engine* e : m->eng) { const int rc = rt_engine_poll(e); if (rc != 1) return rc; }
+    return 1;
+}
+int rt_multi_sync(rt_multi* m) {
+    if (!m) return fail(RT_E_INVALID, "null handle");
+    for (size_t k = m->eng.size(); k-- > 0;) if (int rc = rt_engine_sync(m->eng[k])) return rc;   // the display engine last: it waits for the others' tiles
+    return RT_OK;
+}
+int rt_multi_cancel(rt_multi* m) {
+    if (!m) return fail(RT_E_INVALID, "null handle");
+    for (rt_engine* e : m->eng) if (int rc = rt_engine_cancel(e)) return rc;
+    return RT_OK;
+}
+int rt_multi_clear_frame(rt_multi* m) { return m ? rt_engine_clear_frame(m->eng[0], nullptr) : fail(RT_E_INVALID, "null handle"); }
+int rt_multi_map_frame(rt_multi* m, int wait, const uint8_t** rgba) {
+    if (!m) return fail(RT_E_INVALID, "null handle");
+    if (wait) for (size_t k = m->eng.size(); k-- > 1;) if (int rc = rt_engine_sync(m->eng[k])) return rc;
+    return rt_engine_map_frame(m->eng[0], wait, rgba);
 }
 
 // The entry points above that allocate host memory, behind rt::guard: no exception crosses the C boundary.

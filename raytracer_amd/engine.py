@@ -99,6 +99,18 @@ SIGNATURES = {
     "rt_engine_get_stats": (C.c_int, [_V, C.POINTER(Stats)]),
     "rt_engine_time_kernels": (C.c_int, [_V, C.c_int]),
     "rt_engine_kernel_times": (C.c_int, [_V, f64p]),
+    "rt_multi_create": (C.c_int, [C.POINTER(Config), i32p, C.c_int, _PV]),
+    "rt_multi_destroy": (None, [_V]),
+    "rt_multi_count": (C.c_int, [_V]),
+    "rt_multi_engine": (C.c_void_p, [_V, C.c_int]),
+    "rt_multi_set_scene": (C.c_int, [_V, _V]),
+    "rt_multi_set_camera": (C.c_int, [_V, f32p]),
+    "rt_multi_render": (C.c_int, [_V, C.c_uint32]),
+    "rt_multi_poll": (C.c_int, [_V]),
+    "rt_multi_sync": (C.c_int, [_V]),
+    "rt_multi_cancel": (C.c_int, [_V]),
+    "rt_multi_clear_frame": (C.c_int, [_V]),
+    "rt_multi_map_frame": (C.c_int, [_V, C.c_int, _PV]),
     "rt_engine_eval_math": (C.c_int, [_V, C.c_int, f32p, f32p, f32p, f32p]),
     "rt_engine_eval_rng": (C.c_int, [_V, C.c_int, u32p, u32p, u32p, f32p]),
     "rt_engine_check_division": (C.c_int, [_V, C.c_int, f32p, f32p, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_uint64), f32p]),
@@ -472,3 +484,64 @@ class Engine:
         u = np.zeros(len(key), np.float32)
         _check(self.L.rt_engine_eval_rng(self.h, len(key), key, ctr, r, u))
         return r, u
+
+
+class MultiEngine:
+    """Several GPUs behind one handle in one process (rt_multi): device k renders tiles k, k+n, ...; the first device
+    gathers them with peer-to-peer copies and holds the frame.  A device may be listed more than once."""
+
+    def __init__(self, cfg, device_ids):
+        self.L = lib()
+        ids = np.ascontiguousarray(device_ids, np.int32)
+        h = C.c_void_p()
+        _check(self.L.rt_multi_create(C.byref(cfg), ids, len(ids), C.byref(h)))
+        self.h = h
+        self.cfg = Config()
+        _check(self.L.rt_engine_get_config(self.L.rt_multi_engine(self.h, 0), C.byref(self.cfg)))
+        self._scene = None
+
+    def __del__(self):
+        self.close()
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.rt_multi_destroy(self.h)
+            self.h = None
+
+    def __len__(self):
+        return int(self.L.rt_multi_count(self.h))
+
+    def set_scene(self, scene):
+        _check(self.L.rt_multi_set_scene(self.h, scene.h))
+        self._scene = scene
+
+    def set_camera(self, cam12):
+        _check(self.L.rt_multi_set_camera(self.h, np.ascontiguousarray(cam12, np.float32).reshape(12)))
+
+    def render(self, seed):
+        _check(self.L.rt_multi_render(self.h, seed))
+
+    def poll(self):
+        return bool(_check(self.L.rt_multi_poll(self.h)))
+
+    def sync(self):
+        _check(self.L.rt_multi_sync(self.h))
+
+    def cancel(self):
+        _check(self.L.rt_multi_cancel(self.h))
+
+    def clear_frame(self):
+        _check(self.L.rt_multi_clear_frame(self.h))
+
+    def map_frame(self, wait=True):
+        p = C.c_void_p()
+        _check(self.L.rt_multi_map_frame(self.h, int(wait), C.byref(p)))
+        n = self.cfg.height * self.cfg.width * 4
+        a = np.frombuffer((C.c_uint8 * n).from_address(p.value), np.uint8).reshape(self.cfg.height, self.cfg.width, 4)
+        a.flags.writeable = False
+        return a
+
+    def stats(self, k):
+        st = Stats()
+        _check(self.L.rt_engine_get_stats(self.L.rt_multi_engine(self.h, k), C.byref(st)))
+        return {"paths": int(st.paths), "rays": int(st.rays), "box_tests": int(st.box_tests)}

@@ -403,6 +403,29 @@ def test_cancel_and_host_frame(rt, gpu_default):
     print(f"full frame {t_full * 1e3:.0f} ms, cancelled after {0.33 * t_full * 1e3:.0f} ms: back in {t_cancelled * 1e3:.0f} ms, {done.mean():.2f} of the pixels done")
 
 
+@pytest.mark.parametrize("ids", [[0], [0, 0], [0, 0, 0, 0, 0]])
+def test_several_devices_behind_one_handle(rt, gpu_default, ids):
+    """rt_multi: one process, one engine per listed device, tiles interleaved over them, peer copies to the first one.
+    A one-GPU box lists its device several times, which runs the same code.  Every byte equals the one-engine frame."""
+    W, H, S, B = 333, 187, 3, 5
+    cam = rt.camera_look(CAM_POS, CAM_LOOK)
+    base = make_engine(rt, gpu_default, W, H, S, B, cam).render_frame(3)
+    m = rt.MultiEngine(rt.default_config(width=W, height=H, samples_per_axis=S, bounces=B, tile_w=32, tile_h=32), ids)
+    assert len(m) == len(ids)
+    m.set_scene(gpu_default)
+    m.set_camera(cam)
+    m.clear_frame()
+    m.render(3)
+    assert_bits(m.map_frame(wait=True), base, f"{len(ids)} engines behind one handle")
+    assert m.poll() is True
+    assert sum(m.stats(k)["paths"] for k in range(len(ids))) == W * H * S * S
+    m.render(4)
+    m.cancel()
+    m.sync()
+    m.render(3)
+    assert_bits(m.map_frame(wait=True), base, "frame after a cancelled one")
+
+
 def test_front_end_adapter_matches_the_c_abi(rt, gpu_default, tmp_path):
     """raytracer_amd/compat_demo drives the FrameManager / World / Camera adapter (raytracer_amd/csrc/compat, the
     reference's class interface over the C ABI) like the reference's main loop, at the resolution and quality of the
@@ -419,6 +442,11 @@ def test_front_end_adapter_matches_the_c_abi(rt, gpu_default, tmp_path):
     assert log.returncode == 0, log.stdout + log.stderr
     assert "Frame calculating time" in log.stdout          # LOG_BENCHMARK print of FrameManager::FinishFrame
     raw = np.fromfile(out, np.uint8)
+    # the same front end with the frame split over "two devices" (this GPU listed twice): the same bytes
+    out2 = tmp_path / "frame2.raw"
+    log2 = subprocess.run([demo, "1", str(out2)], env=dict(env, RT_DEVICES="0,0"), capture_output=True, text=True, timeout=110)
+    assert log2.returncode == 0, log2.stdout + log2.stderr
+    assert_bits(np.fromfile(out2, np.uint8), raw, "adapter frame with RT_DEVICES=0,0")
     cfg = rt.default_config()                              # the values of Constants.h
     W, H = cfg.width, cfg.height
     assert raw.size == W * H * 4
@@ -745,6 +773,33 @@ def test_c3_map_and_crop_vs_reference(rt, orc, golden, assets, c3_scene):
     assert_bits(got["radiance"], ref["radiance"], "C3 crop radiance vs the oracle")
     assert_bits(got["rng_draws"], ref["rng_draws"], "C3 crop RNG draws vs the oracle")
     assert_bits(frame[y0:y1, x0:x1], ref["rgba"], "C3 crop colour vs the oracle")
+
+
+@pytest.mark.parametrize("n_ranks", [2, 4, 8])
+def test_c4_rank_split_of_the_large_scene(rt, golden, c3_scene, n_ranks):
+    """C4's workload (the 100 000-primitive scene, tiles interleaved over 2 / 4 / 8 ranks) at a reduced frame size: the
+    shares assembled are the one-rank frame byte for byte, and the shares' ray counts add up to the frame's"""
+    import torch
+    g = golden("scene_c3")
+    scene, _ = c3_scene
+    cam = rt.camera_look(g["cam_pos"], g["cam_look"])
+    W, H, S, B = 640, 360, 2, 8
+    one = make_engine(rt, scene, W, H, S, B, cam)
+    base = one.render_frame(int(g["seed"]))
+    rays = one.stats()["rays"]
+    e = make_engine(rt, scene, W, H, S, B, cam)
+    nb = e.tile_bytes(n_ranks)
+    gathered = torch.zeros(n_ranks * nb, dtype=torch.uint8, device="cuda")
+    share = []
+    for r in range(n_ranks):
+        e.render(int(g["seed"]), rank=r, n_ranks=n_ranks, d_out=gathered.data_ptr() + r * nb)
+        share.append(e.stats()["rays"])
+    out = torch.zeros(H * W * 4, dtype=torch.uint8, device="cuda")
+    e.assemble(gathered.data_ptr(), n_ranks, d_out=out.data_ptr())
+    e.sync()
+    assert_bits(out.cpu().numpy().reshape(H, W, 4), base, f"{n_ranks}-rank split of the large scene")
+    assert sum(share) == rays
+    assert max(share) < 1.5 * rays / n_ranks, f"shares {share} of {rays} rays: interleaved tiles should balance"
 
 
 def test_c3_full_frame_properties(rt, golden, c3_scene):
