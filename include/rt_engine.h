@@ -171,10 +171,11 @@ int rt_engine_map_frame(rt_engine* e, int wait, const uint8_t** rgba);
 /* memset(texturePixels, 0) of FrameManager::StartNewFrame (FrameManager.cpp:13) on the engine's own frame buffer, in
  * stream order (NULL = the engine's stream). */
 int rt_engine_clear_frame(rt_engine* e, void* stream);
-/* FrameManager::TerminateAllThreads (FrameManager.cpp:31-38, state = Quit) without the wait: the render in flight (and
- * only that one) stops taking rays; its remaining launches leave at once and batches that have not been resolved keep
- * what the frame buffer held.  Returns immediately; rt_engine_sync then returns as soon as the rays in flight are done.
- * A render started afterwards is not affected. */
+/* FrameManager::TerminateAllThreads (FrameManager.cpp:31-38, state = Quit) without the wait: of the render in flight (and
+ * only that one) the launch that is running finishes, every later launch leaves at once, and batches that have not been
+ * resolved keep what the frame buffer held.  Returns immediately; rt_engine_sync then returns after what is left of one
+ * launch (milliseconds; tens of milliseconds for a 2^27-path batch of a 100 000-primitive scene).  A render started
+ * afterwards is not affected. */
 int rt_engine_cancel(rt_engine* e);
 /* Per-sample outputs (parity/debug).  rt_engine_keep_samples(e, 1) makes following renders record them; they can be read
  * after an rt_engine_render with n_ranks == 1 on a frame that fits one batch:

@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "librt_engine.so")
+# RT_ENGINE_LIB names another build of the same library (A/B measurements of kernel variants)
+LIB_PATH = os.environ.get("RT_ENGINE_LIB") or os.path.join(HERE, "librt_engine.so")
 ASSET_DIR = os.path.join(os.path.dirname(HERE), "assets")
 
 MAT_NONE, MAT_DIFFUSE, MAT_METAL, MAT_ISOTROPIC, MAT_LIGHT = 0, 1, 2, 3, 4
