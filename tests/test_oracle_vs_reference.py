@@ -36,3 +36,23 @@ def test_random_scenes_oracle_is_the_reference(orc, ref, assets, seed):
             assert_bits(a[k], b[k], f"random scene {seed}: {k}")
     finally:
         ref.free(w)
+
+
+REF_ASSETS = "/root/reference/Raytracer/src/stb_image"
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir(REF_ASSETS), reason="the reference's asset directory is not here")
+def test_asset_decoders_on_every_reference_asset(rt, ref):
+    """the product's PNG decoder and OBJ parser against stb_image (DataUtility.cpp:17-28, 98-109) and LoadOBJ
+    (Object.cpp:349-435) on every asset the reference ships, the ones its compiled-in scene does not use included
+    (Earth.png, Rock.obj); three and four channels, rows flipped as the reference loads them"""
+    import os
+    E = rt.engine
+    for name in ("Earth.png", "skybox12.png", "tree_texture.png"):
+        for channels in (3, 4):
+            want, want_fc = ref.load_image(os.path.join(REF_ASSETS, name), channels)
+            got, got_fc = E.load_png(os.path.join(REF_ASSETS, name), channels)
+            assert got_fc == want_fc, f"{name}: channels in the file"
+            assert_bits(got, want, f"{name} decoded to {channels} channels")
+    for name in ("Rock.obj", "tree.obj"):
+        assert_bits(E.load_obj(os.path.join(REF_ASSETS, name)), ref.load_obj(os.path.join(REF_ASSETS, name)), f"{name} vertices")
