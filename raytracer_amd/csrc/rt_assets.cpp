@@ -167,15 +167,26 @@ bool load_png(const std::string& path, int req_channels, bool flip, std::vector<
     case 6: chans = 4; break;
     default: err = "bad PNG colour type in " + path; return false;
     }
-    // inflate
+    // The filtered data the header announces: one filter byte and the samples of every row, for the whole image or for
+    // each of the seven Adam7 passes.
+    static const int xs[7] = {0, 4, 0, 2, 0, 1, 0}, ys[7] = {0, 0, 4, 0, 2, 0, 1}, dx[7] = {8, 8, 4, 4, 2, 2, 1}, dy[7] = {8, 8, 8, 4, 4, 2, 2};
+    size_t need = 0;
+    if (!interlace) need = (size_t)h * ((size_t)w * chans + 1);
+    else
+        for (int pass = 0; pass < 7; pass++) {
+            const int pw = (w - xs[pass] + dx[pass] - 1) / dx[pass], ph = (h - ys[pass] + dy[pass] - 1) / dy[pass];
+            if (pw > 0 && ph > 0) need += (size_t)ph * ((size_t)pw * chans + 1);
+        }
+    // Deflate cannot expand by more than 1032 : 1, so a file too short for its header is turned away before anything of
+    // the announced size (up to 4 GiB) is allocated.
+    if (idat.size() > ((size_t)1 << 40) || idat.size() * 1032 + 1024 < need) { err = "corrupt PNG data in " + path; return false; }
+    // inflate: both sides are fed to zlib in pieces that fit its 32-bit counters
     std::vector<uint8_t> raw;
     {
         z_stream zs;
         memset(&zs, 0, sizeof zs);
         if (inflateInit(&zs) != Z_OK) { err = "zlib init failed"; return false; }
-        // upper bound: every pass row carries a filter byte (at most 2^15 x 2^15 x 4 + rows: 4 GiB + a little, so both
-        // sides are fed to zlib in pieces that fit its 32-bit counters)
-        raw.resize((size_t)h * ((size_t)w * chans + 1) + 7 * (size_t)(h + 8) + 64);
+        raw.resize(need);
         const size_t piece = (size_t)1 << 30;
         size_t in_at = 0, out_at = 0;
         int rc = Z_OK;
@@ -188,14 +199,14 @@ bool load_png(const std::string& path, int req_channels, bool flip, std::vector<
                 const size_t n_out = std::min(piece, raw.size() - out_at);
                 zs.next_out = raw.data() + out_at; zs.avail_out = (uInt)n_out; out_at += n_out;
             }
-            if (zs.avail_out == 0) break;                          // more data than the header announced
+            if (zs.avail_out == 0) break;                          // more data than the header announced: ignored
             rc = inflate(&zs, Z_NO_FLUSH);
             if (rc == Z_BUF_ERROR && zs.avail_in == 0 && in_at == idat.size()) break;   // the stream ends early
         }
         const size_t got = out_at - zs.avail_out;
         inflateEnd(&zs);
         if (rc != Z_STREAM_END && rc != Z_OK && rc != Z_BUF_ERROR) { err = "zlib inflate failed on " + path; return false; }
-        raw.resize(got);
+        if (got < need) { err = "corrupt PNG data in " + path; return false; }
     }
     std::vector<uint8_t> px((size_t)w * h * chans);
     if (!interlace) {
@@ -203,7 +214,6 @@ bool load_png(const std::string& path, int req_channels, bool flip, std::vector<
         if (!unfilter(raw.data(), raw.size(), h, (size_t)w * chans, chans, img)) { err = "corrupt PNG data in " + path; return false; }
         px.swap(img);
     } else {
-        static const int xs[7] = {0, 4, 0, 2, 0, 1, 0}, ys[7] = {0, 0, 4, 0, 2, 0, 1}, dx[7] = {8, 8, 4, 4, 2, 2, 1}, dy[7] = {8, 8, 8, 4, 4, 2, 2};
         size_t off = 0;
         for (int pass = 0; pass < 7; pass++) {
             int pw = (w - xs[pass] + dx[pass] - 1) / dx[pass], ph = (h - ys[pass] + dy[pass] - 1) / dy[pass];

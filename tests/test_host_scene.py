@@ -134,6 +134,24 @@ def test_error_behaviour_without_gpu(rt):
         E.load_png(os.path.join(ASSETS, "tree.obj"), 3)          # not a PNG
 
 
+def test_damaged_png_files_are_errors(rt, tmp_path):
+    """a file cut short, a header announcing more pixels than the data can hold, and a flipped data byte are all turned
+    away with an error (nothing of the announced size is allocated first, no exception leaves the library)"""
+    import struct
+    import zlib
+    E = rt.engine
+    good = open(os.path.join(ASSETS, "tree_texture.png"), "rb").read()
+    cases = {"cut.png": good[:len(good) // 2], "cut_header.png": good[:20], "flipped.png": good[:4000] + bytes([good[4000] ^ 0x55]) + good[4001:]}
+    # the same file with a header announcing 30000 x 30000 pixels
+    ihdr = struct.pack(">II", 30000, 30000) + good[24:29]
+    cases["huge.png"] = good[:12] + b"IHDR" + ihdr + struct.pack(">I", zlib.crc32(b"IHDR" + ihdr)) + good[33:]
+    for name, data in cases.items():
+        p = tmp_path / name
+        p.write_bytes(data)
+        with pytest.raises(rt.RtError):
+            E.load_png(str(p), 4)
+
+
 def test_engine_refuses_to_run_without_a_gpu(rt):
     """no CPU fallback: creating an engine without a HIP device is an error"""
     import torch
