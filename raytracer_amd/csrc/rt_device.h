@@ -96,13 +96,19 @@ __device__ inline float pm_sinf(float x) {
     return (float)res;
 }
 __device__ inline double pm_atan_pos(double x) {
-    double hi = 0.0, lo = 0.0;
+    // the four reductions of fdlibm's s_atan.c; numerator and denominator are picked by selects and divided once: the lanes
+    // of a wave fall into all of the ranges, and a division per range would be executed four times over
     int id = -1;
-    if (x < 0.4375) id = -1;
-    else if (x < 0.6875) { id = 0; x = (2.0 * x - 1.0) / (2.0 + x); hi = 4.63647609000806093515e-01; lo = 2.26987774529616870924e-17; }
-    else if (x < 1.1875) { id = 1; x = (x - 1.0) / (x + 1.0); hi = 7.85398163397448278999e-01; lo = 3.06161699786838301793e-17; }
-    else if (x < 2.4375) { id = 2; x = (x - 1.5) / (1.0 + 1.5 * x); hi = 9.82793723247329054082e-01; lo = 1.39033110312309984516e-17; }
-    else { id = 3; x = -1.0 / x; hi = 1.57079632679489655800e+00; lo = 6.12323399573676603587e-17; }
+    double num = x, den = 1.0, hi = 0.0, lo = 0.0;
+    if (!(x < 0.4375)) {
+        const bool r0 = x < 0.6875, r1 = x < 1.1875, r2 = x < 2.4375;
+        id = r0 ? 0 : (r1 ? 1 : (r2 ? 2 : 3));
+        num = r0 ? 2.0 * x - 1.0 : (r1 ? x - 1.0 : (r2 ? x - 1.5 : -1.0));
+        den = r0 ? 2.0 + x : (r1 ? x + 1.0 : (r2 ? 1.0 + 1.5 * x : x));
+        hi = r0 ? 4.63647609000806093515e-01 : (r1 ? 7.85398163397448278999e-01 : (r2 ? 9.82793723247329054082e-01 : 1.57079632679489655800e+00));
+        lo = r0 ? 2.26987774529616870924e-17 : (r1 ? 3.06161699786838301793e-17 : (r2 ? 1.39033110312309984516e-17 : 6.12323399573676603587e-17));
+        x = num / den;
+    }
     const double z = x * x, w = z * z;
     const double s1 = z * (3.33333333333329318027e-01 + w * (1.42857142725034663711e-01 + w * (9.09088713343650656196e-02 +
                       w * (6.66107313738753120669e-02 + w * (4.97687799461593236017e-02 + w * 1.62858201153657823623e-02)))));

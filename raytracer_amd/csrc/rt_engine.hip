@@ -633,6 +633,7 @@ struct rt_engine {
     bool debug_valid = false;
     int n_cus = 0;
     Tune tune{32, 16, 8, 256, 16, 64, 16, 1};
+    int quorum_mem = 24;                // Tune::quorum for scenes read from memory (RT_QUORUM sets both)
     int win[4] = {0, 0, 0, 0};          // x0, y0, width, height of the render window
     // statistics of the last render
     std::vector<uint32_t> h_counts;     // per batch: counts (B + 2), cursors (B + 2)
@@ -703,8 +704,13 @@ void launch_intersect(rt_engine* e, hipStream_t st, const Cfg& g, const Batch& b
     const int blocks = e->n_cus * 2;
     // the kernel is compiled with and without fog support: a scene without fog pays nothing for it
     const bool fog = e->sc.has_fog != 0;
+    // a scene read from memory: every iteration of the traversal loop ends in a round trip to the cache, so the loop
+    // is left to the primitive tests only when fewer lanes can go on (measured on the 100 000-primitive scene: 8 -> 24
+    // lanes, 3.5 % of the frame)
+    Tune tune = e->tune;
+    if (!e->staged_bytes) tune.quorum = e->quorum_mem;
 #define RT_LAUNCH_INTERSECT(STAGED, FOG, LDS_BYTES) \
-    hipLaunchKernelGGL((intersect_kernel<FIRST, STAGED, FOG>), dim3(blocks), dim3(IBLOCK), LDS_BYTES, st, e->sc, e->cam, g, bt, q, pass, e->dbg, e->tune)
+    hipLaunchKernelGGL((intersect_kernel<FIRST, STAGED, FOG>), dim3(blocks), dim3(IBLOCK), LDS_BYTES, st, e->sc, e->cam, g, bt, q, pass, e->dbg, tune)
     if (e->staged_bytes) { if (fog) RT_LAUNCH_INTERSECT(true, true, e->staged_bytes); else RT_LAUNCH_INTERSECT(true, false, e->staged_bytes); }
     else { if (fog) RT_LAUNCH_INTERSECT(false, true, 0); else RT_LAUNCH_INTERSECT(false, false, 0); }
 #undef RT_LAUNCH_INTERSECT
@@ -830,7 +836,7 @@ int init_engine(rt_engine* e, const rt_config* cfg) {
 #endif
     if (const char* v = getenv("RT_REFILL_AT")) e->tune.refill_at = std::max(1, std::min(64, atoi(v)));
     if (const char* v = getenv("RT_REFILL_AT_BOUNCE")) e->tune.refill_at_bounce = std::max(1, std::min(64, atoi(v)));
-    if (const char* v = getenv("RT_QUORUM")) e->tune.quorum = std::max(1, std::min(65, atoi(v)));
+    if (const char* v = getenv("RT_QUORUM")) e->tune.quorum = e->quorum_mem = std::max(1, std::min(65, atoi(v)));
     if (const char* v = getenv("RT_CHUNK")) e->tune.chunk = std::max(64, atoi(v) & ~63);
     if (const char* v = getenv("RT_MIN_CHUNK")) e->tune.min_chunk = std::max(8, atoi(v) & ~7);
     if (const char* v = getenv("RT_GUIDE")) e->tune.guide = std::max(1, std::min(64, atoi(v)));

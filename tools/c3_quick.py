@@ -9,7 +9,7 @@ import torch
 import bench
 import raytracer_amd as rt
 
-scene, cam = bench.build_scene(rt, "c3")
+scene, cam, _ = bench.build_scene(rt, "c3")
 e = rt.Engine(rt.default_config(width=960, height=540, samples_per_axis=8, bounces=8))
 e.set_scene(scene)
 e.set_camera(cam)
