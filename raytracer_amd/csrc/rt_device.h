@@ -537,7 +537,9 @@ __device__ __forceinline__ void walker_start(const Scene& sc, const Store& st, W
 //     magnitude the exactly rounded quotients order the same way (and a quotient's sign is that of its product), so the
 //     decision stands.  Only if some lane is closer than that does the wave compute the exact quotients (the four packed
 //     FMAs per axis) and decide again — a few box tests in a million;
-//   * the loads land in the registers that already hold the entry (tied operands): nothing is copied;
+//   * the loads land in the registers that already hold the entry: nothing is copied (from LDS as tied operands; from
+//     memory the entry is bound to v22..v29, because a 16-byte load needs a register quadruple and the operands are
+//     pairs);
 //   * the lanes that act are enabled through exec inside the block (restored before every test and at the end), so the
 //     surrounding control flow is wave-uniform.
 // v2..v21 are used as scratch registers by name because the halves of a register pair cannot be named through operands.
@@ -757,23 +759,18 @@ __device__ __forceinline__ void box_steps(const Store& st, Walker& w, int quorum
                  "s_and_b64 exec, %[saved], %[mall]\n\t"
                  RT_BOX_COUNT
                  "v_lshlrev_b32_e32 v2, 5, %[i]\n\t"
-                 "global_load_dwordx4 v[10:13], v2, %[base]\n\t"
-                 "global_load_dwordx4 v[14:17], v2, %[base] offset:16\n\t"
+                 "global_load_dwordx4 v[22:25], v2, %[base]\n\t"
+                 "global_load_dwordx4 v[26:29], v2, %[base] offset:16\n\t"
                  "s_waitcnt vmcnt(0)\n\t"
-                 "v_pk_mov_b32 %[e01], v[10:11], v[10:11] op_sel:[0,1]\n\t"
-                 "v_pk_mov_b32 %[e23], v[12:13], v[12:13] op_sel:[0,1]\n\t"
-                 "v_pk_mov_b32 %[e45], v[14:15], v[14:15] op_sel:[0,1]\n\t"
-                 "v_mov_b32_e32 %[sk], v16\n\t"
-                 "v_mov_b32_e32 %[rho], v17\n\t"
                  "s_mov_b64 exec, %[saved]\n\t"
                  "s_bcnt1_i32_b64 %[cntS], %[m]\n\t"
                  "s_add_u32 %[nbox], %[nbox], %[cntS]\n\t"
                  "s_cmp_ge_u32 %[cntS], %[quorum]\n\t"
                  "s_cbranch_scc1 1b\n\t"
                  "2:\n\t"
-                 : [e01] "+v"(w.e01), [e23] "+v"(w.e23), [e45] "+v"(w.e45), [sk] "+v"(w.sk), [i] "+v"(w.i), [f0] "+v"(w.f0),
+                 : [e01] "+{v[22:23]}"(w.e01), [e23] "+{v[24:25]}"(w.e23), [e45] "+{v[26:27]}"(w.e45), [sk] "+{v28}"(w.sk), [i] "+v"(w.i), [f0] "+v"(w.f0),
                    [f1] "+v"(w.f1), [f2] "+v"(w.f2), [cnt] "+v"(w.cnt), [m] "=&s"(m), [m2] "=&s"(m2), [m3] "=&s"(m3),
-                   [mall] "=&s"(mall), [saved] "=&s"(saved), [cntS] "=&s"(n_inner), [m4] "=&s"(m4), [rho] "+v"(w.rho), [nbox] "+s"(nb) RT_BOX_COUNT_OPERANDS
+                   [mall] "=&s"(mall), [saved] "=&s"(saved), [cntS] "=&s"(n_inner), [m4] "=&s"(m4), [rho] "+{v29}"(w.rho), [nbox] "+s"(nb) RT_BOX_COUNT_OPERANDS
                  : [p0] "v"(w.p0), [p1] "v"(w.p1), [p2] "v"(w.p2), [p3] "v"(w.p3), [p4] "v"(w.p4), [px] "s"(px), [py] "s"(py),
                    [pz] "s"(pz), [base] "s"(base), [usable] "s"(usable), [quorum] "s"(quorum), [ck] "v"(w.cull_k), [cbase] "v"(w.cull_base)
                  : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18",
