@@ -305,16 +305,31 @@ class Job:
             self.dist.destroy_process_group()
 
 
-def run_workload(job, rt, workload, steps, warmup, batch_paths=0):
-    """warm up, then time `steps` frames between barriers; returns this rank's measurements plus the reductions"""
+def run_workload(job, rt, workload, steps, warmup, batch_paths=0, in_flight=1):
+    """warm up, then time `steps` frames between barriers; returns this rank's measurements plus the reductions.
+    in_flight > 1: that many engines take the frames in turn (raytracer_amd.distributed.TileRenderer); the figures of
+    one frame (rays, kernel times) are the first engine's"""
     from raytracer_amd.distributed import TileRenderer
     desc, W, H, S, B = WORKLOADS[workload]
     scene, cam, build_s = build_scene(rt, workload)
-    eng = rt.Engine(rt.default_config(width=W, height=H, samples_per_axis=S, bounces=B, device=job.local_rank,
-                                      max_batch_paths=batch_paths))
-    eng.set_scene(scene)
-    eng.set_camera(cam)
-    tr = TileRenderer(eng, job.device, job.rank, job.world)
+    engs = []
+    for _ in range(max(1, in_flight)):
+        eng = rt.Engine(rt.default_config(width=W, height=H, samples_per_axis=S, bounces=B, device=job.local_rank,
+                                          max_batch_paths=batch_paths))
+        eng.set_scene(scene)
+        eng.set_camera(cam)
+        engs.append(eng)
+    eng = engs[0]
+    tr = TileRenderer(engs, job.device, job.rank, job.world)
+    if len(engs) > 1:
+        # set-up, not a step: every engine renders its share once (no gather), so that none of them meets its first
+        # launch inside the timed region when there are fewer warm-up steps than engines
+        import torch
+        scratch = torch.zeros(max(eng.tile_bytes(job.world), W * H * 4), dtype=torch.uint8, device=job.device)
+        for e_ in engs:
+            e_.render(SEED, job.rank, job.world, scratch.data_ptr())
+            e_.sync()
+        del scratch
     frame_ms = []
     for _ in range(warmup):
         tr.render_frame(SEED)
@@ -345,12 +360,24 @@ def run_workload(job, rt, workload, steps, warmup, batch_paths=0):
     kern_ms, kern_launches = eng.kernel_times()
     eng.time_kernels(False)
     st = eng.stats()                       # this rank's share of one frame (every step renders the same frame)
+    one_ms = None
+    if len(engs) > 1:
+        # beside the throughput with several frames in flight: the time of a frame that has the GPUs to itself
+        tr1 = TileRenderer(eng, job.device, job.rank, job.world)
+        tr1.render_frame(SEED)
+        job.barrier()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            tr1.render_frame(SEED)
+            job.barrier()
+        one_ms = job.reduce([(time.perf_counter() - t1) / 5 * 1e3], "MAX")[0]
     dt = job.reduce([dt], "MAX")[0]
     rays_frame, paths_frame, box_frame = job.reduce([st["rays"], st["paths"], st["box_tests"]], "SUM")
     per_rank = job.gather_all([st["rays"], kern_ms, kern_launches])
-    return {"desc": desc, "W": W, "H": H, "S": S, "B": B, "eng": eng, "tr": tr, "dt": dt, "steps": steps, "frame_ms": frame_ms,
+    return {"desc": desc, "W": W, "H": H, "S": S, "B": B, "eng": eng, "engs": engs, "tr": tr, "dt": dt, "steps": steps, "frame_ms": frame_ms,
             "kern_ms": max(per_rank[1]), "kern_launches": kern_launches, "stats": st, "rays_frame": rays_frame,
-            "paths_frame": paths_frame, "box_frame": box_frame, "per_rank": per_rank, "scene_build_s": build_s}
+            "paths_frame": paths_frame, "box_frame": box_frame, "per_rank": per_rank, "scene_build_s": build_s,
+            "one_in_flight_ms": one_ms}
 
 
 def c5_on_one_gpu(job, rt, steps):
@@ -420,6 +447,9 @@ def main():
     ap.add_argument("--no-also", action="store_true", help="only the headline workload (profiling runs)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--batch-paths", type=int, default=0)
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="engines per rank taking the frames in turn; 0 = 3 from four GPUs on, else 1 (what a rank's share of "
+                         "the frame measured best with on one GPU: tools/frames_in_flight.py)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks all on GPU 0 with a gloo group (staged through the host): checks the multi-process "
                          "path on a one-GPU box; the number it prints is not a measurement")
@@ -431,7 +461,8 @@ def main():
     threads = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))
     with_cpu = (not args.no_cpu_baseline) and world == 1
 
-    r = run_workload(job, rt, args.workload, args.steps, args.warmup, args.batch_paths)
+    in_flight = args.frames_in_flight or (3 if world >= 4 and args.workload == "c2" else 1)
+    r = run_workload(job, rt, args.workload, args.steps, args.warmup, args.batch_paths, in_flight)
     desc, W, H, S, B = r["desc"], r["W"], r["H"], r["S"], r["B"]
     out = None
     if rank == 0:
@@ -460,9 +491,11 @@ def main():
             "ms_per_step": r["dt"] / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic" if not args.rehearse_on_one_gpu else "synthetic (rehearsal: all ranks on one GPU, not a measurement)",
             "config": {"workload": desc, "width": W, "height": H, "spp": S * S, "bounces": B, "rays_per_frame": r["rays_frame"],
-                       "paths_per_frame": r["paths_frame"], "parallelism": f"tiles{world}", "batch_paths": r["eng"].cfg.max_batch_paths,
+                       "paths_per_frame": r["paths_frame"], "parallelism": f"tiles{world}", "frames_in_flight": in_flight, "batch_paths": r["eng"].cfg.max_batch_paths,
                        "build_key": f"0x{BUILD_KEY:08X}", "scene_build_s": r["scene_build_s"], "kernel_sources": rt.engine.source_hash()},
             "ms_per_frame": r["dt"] / args.steps * 1e3,
+            # with several frames in flight ms_per_step is the time between finished frames; this is one frame alone
+            "ms_per_frame_one_in_flight": r["one_in_flight_ms"],
             "frame_latency_ms": ({"p50": float(np.percentile(fm, 50)), "p99": float(np.percentile(fm, 99)), "max": float(max(fm))} if fm else None),
             "roofline": roof, "roofline_hbm": hbm, "cpu_baseline": cpu,
             # what each rank did in the last frame: with tiles interleaved the rays should be even; the slowest rank's
@@ -476,7 +509,8 @@ def main():
             spread = key_spread(rt, r["eng"], r["tr"], W, H, S, B, threads if with_cpu else 0)
             if out is not None:
                 out["build_key_spread"] = spread
-        r["eng"].close()
+        for e_ in r["engs"]:
+            e_.close()
         also = {}
         r3 = run_workload(job, rt, "c3", 2, 1)
         if rank == 0:
@@ -487,7 +521,8 @@ def main():
                           "rays_per_frame": r3["rays_frame"], "scene_build_s": r3["scene_build_s"], "roofline": roof3, "cpu_baseline": cpu3,
                           "per_rank": {"rays_min_max": [min(r3["per_rank"][0]), max(r3["per_rank"][0])],
                                        "intersect_kernel_ms_min_max": [min(r3["per_rank"][1]), max(r3["per_rank"][1])]}}
-        r3["eng"].close()
+        for e_ in r3["engs"]:
+            e_.close()
         if world == 1:
             also["c5"] = c5_on_one_gpu(job, rt, 240)
         else:
@@ -496,7 +531,8 @@ def main():
                 fm = r5["frame_ms"]
                 also["c5"] = {"workload": r5["desc"], "frames": 240, "includes": "render + tile gather + device-to-host copy on the display rank",
                               "frame_latency_ms": {"p50": float(np.percentile(fm, 50)), "p99": float(np.percentile(fm, 99)), "max": float(max(fm))}}
-            r5["eng"].close()
+            for e_ in r5["engs"]:
+                e_.close()
         if out is not None:
             out["also"] = also
     if out is not None:

@@ -225,12 +225,12 @@ __device__ __forceinline__ Store stage_scene(const Scene& sc, float4* smem) {
 __device__ __forceinline__ uint32_t range_size(uint32_t n_stripes, uint32_t r) { return r < n_stripes ? ((n_stripes - r + NCUR - 1) / NCUR) * STRIPE : 0u; }
 
 // ---- intersect (World.cpp:105-119) ----------------------------------------------------------------------------------
-template <bool FIRST, bool STAGED, bool FOG>
-__global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cfg g, Batch bt, Queues q, int pass, Debug dbg, Tune tune) {
+template <bool FIRST, bool STAGED, bool FOG, int BLOCK = IBLOCK, int MIN_WAVES = 1>
+__global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, Cam cam, Cfg g, Batch bt, Queues q, int pass, Debug dbg, Tune tune) {
     extern __shared__ float4 smem[];
     const uint32_t n_in = FIRST ? (uint32_t)bt.n_pixels * (uint32_t)(g.S * g.S) : q.counts[pass];
     // a pass with few rays: blocks beyond one smallest reservation per wave leave before they copy the scene
-    const uint32_t blocks_used = min((uint32_t)gridDim.x, n_in / ((uint32_t)tune.min_chunk * (IBLOCK / 64)) + 1u);
+    const uint32_t blocks_used = min((uint32_t)gridDim.x, n_in / ((uint32_t)tune.min_chunk * (BLOCK / 64)) + 1u);
     if (n_in == 0u || blockIdx.x >= blocks_used || cancelled(bt)) return;
     const Store st = stage_scene<STAGED>(sc, smem);
     const int qin = (pass + 1) & 1;
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(IBLOCK) void intersect_kernel(Scene sc, Cam cam, Cf
     // the wave owns queue positions [mine, mine_end); it reserves CHUNK more with one atomic when they run out
     uint32_t mine = 0, mine_end = 0, mine_range = 0;   // as offsets of range mine_range
     // few rays in the pass: smaller reservations, so that every wave of the grid gets some
-    const uint32_t waves = blocks_used * (IBLOCK / 64);
+    const uint32_t waves = blocks_used * (BLOCK / 64);
     uint32_t chunk = (n_in / (waves * (uint32_t)tune.guide)) & ~7u;
     chunk = chunk < (uint32_t)tune.min_chunk ? (uint32_t)tune.min_chunk : (chunk > (uint32_t)tune.chunk ? (uint32_t)tune.chunk : chunk);
     bool drained = false;   // wave-uniform: every queue position has been handed out
@@ -711,6 +711,10 @@ void launch_intersect(rt_engine* e, hipStream_t st, const Cfg& g, const Batch& b
     if (!e->staged_bytes) tune.quorum = e->quorum_mem;
 #define RT_LAUNCH_INTERSECT(STAGED, FOG, LDS_BYTES) \
     hipLaunchKernelGGL((intersect_kernel<FIRST, STAGED, FOG>), dim3(blocks), dim3(IBLOCK), LDS_BYTES, st, e->sc, e->cam, g, bt, q, pass, e->dbg, tune)
+    if (e->staged_bytes && !fog && !FIRST && getenv("RT_BLOCK640")) {
+        hipLaunchKernelGGL((intersect_kernel<false, true, false, 640, 5>), dim3(blocks), dim3(640), e->staged_bytes, st, e->sc, e->cam, g, bt, q, pass, e->dbg, tune);
+        return;
+    }
     if (e->staged_bytes) { if (fog) RT_LAUNCH_INTERSECT(true, true, e->staged_bytes); else RT_LAUNCH_INTERSECT(true, false, e->staged_bytes); }
     else { if (fog) RT_LAUNCH_INTERSECT(false, true, 0); else RT_LAUNCH_INTERSECT(false, false, 0); }
 #undef RT_LAUNCH_INTERSECT
@@ -828,6 +832,7 @@ int init_engine(rt_engine* e, const rt_config* cfg) {
     // not of an engine or a scene, so every engine sets the same value
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<false, true, false, 640, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
 #ifdef RT_PROFILE

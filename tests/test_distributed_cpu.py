@@ -82,7 +82,7 @@ def oracle_frame():
     return s.render(O.camera((0, 3, -10), (0, 0, 1)), W, H, S, B, SEED, threads=2, want=("rgba",))["rgba"]
 
 
-def worker(rank, world, port, result):
+def worker(rank, world, port, result, in_flight=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -90,8 +90,9 @@ def worker(rank, world, port, result):
         sys.path.insert(0, ROOT)
         from raytracer_amd.distributed import TileRenderer
         full = oracle_frame()
-        tr = TileRenderer(OracleTileEngine(full), "cpu", rank, world)
-        frame = tr.render_frame(SEED)
+        tr = TileRenderer([OracleTileEngine(full) for _ in range(in_flight)], "cpu", rank, world)
+        for _ in range(2 * in_flight - 1):     # every slot takes a frame, the first ones twice
+            frame = tr.render_frame(SEED)
         if rank == 0:
             got = tr.frame_numpy()
             result["equal"] = bool(np.array_equal(got, full))
@@ -111,6 +112,16 @@ def test_tile_partition_and_gather_gloo(world):
         mp.spawn(worker, args=(world, port, result), nprocs=world, join=True)
         assert result["equal"], "gathered + assembled frame differs from the single-process frame"
         assert result["nonzero"] == W * H
+
+
+def test_several_frames_in_flight_gloo():
+    """three slots (engine, buffers and stream each) take the frames of a sequence in turn: the gathers of all ranks
+    must still pair up frame by frame"""
+    port = 29700 + (os.getpid() % 200)
+    with mp.Manager() as m:
+        result = m.dict()
+        mp.spawn(worker, args=(2, port, result, 3), nprocs=2, join=True)
+        assert result["equal"] and result["nonzero"] == W * H
 
 
 def test_single_rank_needs_no_process_group():

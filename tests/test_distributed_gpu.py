@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 W, H, S, B, SEED = 333, 190, 2, 4, 11
 
 
-def worker(rank, world, port, result):
+def worker(rank, world, port, result, in_flight=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -25,11 +25,14 @@ def worker(rank, world, port, result):
         import raytracer_amd as rt
         from raytracer_amd.distributed import TileRenderer
         scene = rt.default_scene(0x5EED0001)
-        eng = rt.Engine(rt.default_config(width=W, height=H, samples_per_axis=S, bounces=B, device=0, tile_w=32, tile_h=32))
-        eng.set_scene(scene)
-        eng.set_camera(rt.camera_look((0.0, 3.0, -10.0), (0.0, 0.0, 1.0)))
-        tr = TileRenderer(eng, "cuda:0", rank, world)
-        for _ in range(2):                         # twice: buffers are reused between frames
+        engs = []
+        for _ in range(in_flight):
+            eng = rt.Engine(rt.default_config(width=W, height=H, samples_per_axis=S, bounces=B, device=0, tile_w=32, tile_h=32))
+            eng.set_scene(scene)
+            eng.set_camera(rt.camera_look((0.0, 3.0, -10.0), (0.0, 0.0, 1.0)))
+            engs.append(eng)
+        tr = TileRenderer(engs, "cuda:0", rank, world)
+        for _ in range(2 * in_flight):             # every slot twice: buffers are reused between frames
             frame = tr.render_frame(SEED)
         if rank == 0:
             got = tr.frame_numpy()
@@ -50,6 +53,16 @@ def test_two_processes_one_frame(world):
         result = m.dict()
         mp.spawn(worker, args=(world, port, result), nprocs=world, join=True)
         assert result["equal"], "gathered + assembled frame differs from the single-process frame"
+        assert result["lit"] == W * H
+
+
+def test_several_frames_in_flight():
+    """two ranks with three frames in flight each (three engines, streams and buffer sets per rank)"""
+    port = 29900 + (os.getpid() % 80)
+    with mp.Manager() as m:
+        result = m.dict()
+        mp.spawn(worker, args=(2, port, result, 3), nprocs=2, join=True)
+        assert result["equal"], "frame of a pipelined sequence differs from the single-process frame"
         assert result["lit"] == W * H
 
 
