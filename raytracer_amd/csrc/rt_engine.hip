@@ -224,6 +224,24 @@ __device__ __forceinline__ Store stage_scene(const Scene& sc, float4* smem) {
 // end are skipped when they come up)
 __device__ __forceinline__ uint32_t range_size(uint32_t n_stripes, uint32_t r) { return r < n_stripes ? ((n_stripes - r + NCUR - 1) / NCUR) * STRIPE : 0u; }
 
+// A by-value kernel argument read again from the kernarg segment (scalar loads, cached).  The persistent kernels below
+// use some arguments only in a part that runs now and then (the camera, frame and batch records: 62 dwords that only the
+// generation of camera rays reads); held in scalar registers for the whole kernel they push other values out into lanes
+// of a vector register, and every use of those costs a vector instruction.  The pointer is passed through an empty asm
+// statement so that the loads stay where they are written instead of being hoisted out of the loop.
+struct IntersectArgs { Scene sc; Cam cam; Cfg g; Batch bt; Queues q; int pass; Debug dbg; Tune tune; };   // the kernel's parameter list
+template <typename T>
+__device__ __forceinline__ T kernarg_read(size_t offset) {
+    typedef const __attribute__((address_space(4))) uint32_t* KP;
+    KP p = (KP)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + offset);
+    asm volatile("" : "+s"(p));
+    T r;
+    uint32_t* d = reinterpret_cast<uint32_t*>(&r);
+#pragma unroll
+    for (size_t k = 0; k < sizeof(T) / 4; k++) d[k] = p[k];
+    return r;
+}
+
 // ---- intersect (World.cpp:105-119) ----------------------------------------------------------------------------------
 template <bool FIRST, bool STAGED, bool FOG, int BLOCK = IBLOCK, int MIN_WAVES = 1>
 __global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, Cam cam, Cfg g, Batch bt, Queues q, int pass, Debug dbg, Tune tune) {
@@ -296,9 +314,21 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, C
             else {
                 const uint32_t o = mine + (uint32_t)__popcll(idle & below);
                 const uint32_t idx = ((o / STRIPE) * NCUR + mine_range) * STRIPE + o % STRIPE;
-                if (walker_is_idle(w) && o < mine_end && idx < n_in) {
+                if (FIRST) {
+                    // camera, frame and batch records: read here, not kept in registers between refills
+                    const Cam cam_now = kernarg_read<Cam>(offsetof(IntersectArgs, cam));
+                    const Cfg g_now = kernarg_read<Cfg>(offsetof(IntersectArgs, g));
+                    const Batch bt_now = kernarg_read<Batch>(offsetof(IntersectArgs, bt));
+                    if (walker_is_idle(w) && o < mine_end && idx < n_in) {
+                        Ray ray; Rng rng; uint32_t slot, depth;
+                        if (fetch_ray<true>(cam_now, g_now, bt_now, q, qin, dbg, idx, ray, rng, slot, depth, FOG)) {
+                            my_idx = idx;
+                            walker_start<CULL>(sc, st, w, ray, rng);
+                        }
+                    }
+                } else if (walker_is_idle(w) && o < mine_end && idx < n_in) {
                     Ray ray; Rng rng; uint32_t slot, depth;
-                    if (fetch_ray<FIRST>(cam, g, bt, q, qin, dbg, idx, ray, rng, slot, depth, FOG)) {
+                    if (fetch_ray<false>(cam, g, bt, q, qin, dbg, idx, ray, rng, slot, depth, FOG)) {
                         my_idx = idx;
                         walker_start<CULL>(sc, st, w, ray, rng);
                     }
@@ -401,7 +431,15 @@ __global__ __launch_bounds__(256) void shade_kernel(Scene sc, Cam cam, Cfg g, Ba
         Rng rng;
         uint32_t slot = 0, depth = 0;
         ray.o = mk(0, 0, 0); ray.d = mk(0, 0, 1); rng.key = 0; rng.ctr = 0;
-        const bool live = i < n_in && fetch_ray<FIRST>(cam, g, bt, q, qin, dbg, i, ray, rng, slot, depth, FIRST);
+        // the frame and batch records are read from the kernarg segment where they are used (see kernarg_read): the
+        // parameter list begins like the intersect kernel's
+        const Cfg g_now = kernarg_read<Cfg>(offsetof(IntersectArgs, g));
+        const Batch bt_now = kernarg_read<Batch>(offsetof(IntersectArgs, bt));
+        bool live = i < n_in;
+        if (FIRST) {
+            const Cam cam_now = kernarg_read<Cam>(offsetof(IntersectArgs, cam));
+            live = live && fetch_ray<true>(cam_now, g_now, bt_now, q, qin, dbg, i, ray, rng, slot, depth, true);
+        } else live = live && fetch_ray<false>(cam, g_now, bt_now, q, qin, dbg, i, ray, rng, slot, depth, false);
         bool alive = false;        // continues into the next pass
         Ray next = ray;
         if (live) {
@@ -409,7 +447,7 @@ __global__ __launch_bounds__(256) void shade_kernel(Scene sc, Cam cam, Cfg g, Ba
             if (sc.has_fog) rng.ctr = q.hit_ctr[i];      // fog volumes drew random numbers during the traversal
             Closest c;
             c.dist = hr.x; c.best = __float_as_int(hr.y); c.u = hr.z; c.v = hr.w; c.hit = c.best != -1;
-            alive = shade_ray<FIRST>(sc, g, bt, q, dbg, ray, rng, slot, depth, c, next);
+            alive = shade_ray<FIRST>(sc, g_now, bt_now, q, dbg, ray, rng, slot, depth, c, next);
         }
         // compact: survivors of this wave (ballot + prefix count) take consecutive places in the block's staging tile
         const unsigned long long mask = __ballot(alive);
