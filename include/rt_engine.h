@@ -57,6 +57,10 @@ typedef struct rt_config {
  * memory the engine skips boxes that provably lie behind the closest hit found so far (same results, fewer box tests);
  * this flag makes it visit them all, as the reference does — for comparisons. */
 #define RT_FLAG_NO_CULL 1
+/* A scene that fits is copied into on-chip memory by every block of the traversal kernel; this flag makes the kernel read
+ * it from device memory as it reads large scenes — the same results through the other variant of the kernel, for
+ * comparisons and tests. */
+#define RT_FLAG_NO_LDS 2
 void rt_config_defaults(rt_config* cfg);   /* the values of Constants.h:4-17 */
 
 /* ---------------------------------------------------------------------------------------------------------

@@ -832,13 +832,22 @@ __device__ __forceinline__ void tri_finish_step(const Scene& sc, const Store& st
 }
 // Entries that change the lane's state beyond its position; they wait until every noted leaf has been tested.  Returns
 // true when the ray has finished (closest hit known, plane list merged); the lane is idle from then on.
-__device__ __forceinline__ bool walker_special(const Scene& sc, const Store& st, Walker& w) {
+// RELOAD: the ray as given is not kept in registers while the lane is inside an instance (ten registers: what decides
+// whether a fifth wave fits a SIMD); on the way out it is read again from the queue record it came from (outer_a,
+// outer_b: the two halves of record `outer_idx`) and its reciprocals are computed again, bit for bit as at the start.
+template <bool RELOAD = false>
+__device__ __forceinline__ bool walker_special(const Scene& sc, const Store& st, Walker& w, const float4* outer_a = nullptr, const float4* outer_b = nullptr, uint32_t outer_idx = 0) {
     bool done = false;
     const int kind = sk_kind(w.sk);
     if (kind == rt::ENT_END) {
         if (w.inst >= 0) {   // PolygonMesh and its wrappers return to the top level
             w.i = w.resume; w.inst = -1; w.stale = sc.stale_entry;
-            w.p0 = w.s0; w.p1 = w.s1; w.p2 = w.s2; w.p3 = w.s3; w.p4 = w.s4; w.usable = w.s_usable;
+            if (RELOAD) {
+                const float4 a = outer_a[outer_idx], b = outer_b[outer_idx];
+                Ray r;
+                r.o = mk(a.x, a.y, a.z); r.d = mk(a.w, b.x, b.y);
+                walker_set_ray(w, r, sc.fast_div_ok != 0);
+            } else { w.p0 = w.s0; w.p1 = w.s1; w.p2 = w.s2; w.p3 = w.s3; w.p4 = w.s4; w.usable = w.s_usable; }
         } else {
             const Ray top = walker_ray(w);
             for (int p = 0; p < sc.n_planes; p++) {   // YPlane::Intersect (Object.cpp:139-149), merged as World.cpp:110-118
@@ -853,7 +862,7 @@ __device__ __forceinline__ bool walker_special(const Scene& sc, const Store& st,
         const int ii = sk_payload(w.sk);
         const float4* I = st.inst + (size_t)ii * rt::RT_INST_F4;
         const float4 i0 = I[0], i1 = I[1], i2 = I[2], i3 = I[3];
-        w.s0 = w.p0; w.s1 = w.p1; w.s2 = w.p2; w.s3 = w.p3; w.s4 = w.p4; w.s_usable = w.usable;
+        if (!RELOAD) { w.s0 = w.p0; w.s1 = w.p1; w.s2 = w.p2; w.s3 = w.p3; w.s4 = w.p4; w.s_usable = w.usable; }
         walker_set_ray(w, to_instance(i0, i1, i2, walker_ray(w)), sc.fast_div_ok != 0);
         w.resume = w.i + 1;
         w.stale = (w.i == sc.stale_entry) ? __float_as_int(i3.y) : -1;
@@ -871,8 +880,9 @@ __device__ __forceinline__ bool walker_special(const Scene& sc, const Store& st,
 }
 // One round for a wave: the traversal loop; then primitive tests, repeated while at least `prim_quorum` lanes have a
 // noted leaf; then the state-changing entries of lanes that have none left.  Returns true in lanes whose ray finished.
-template <bool LDS, bool FOG>
-__device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Walker& w, int quorum, int prim_quorum, int finish_quorum, Prof& prof, uint32_t& n_box) {
+template <bool LDS, bool FOG, bool RELOAD = false>
+__device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Walker& w, int quorum, int prim_quorum, int finish_quorum, Prof& prof, uint32_t& n_box,
+                                           const float4* outer_a = nullptr, const float4* outer_b = nullptr, uint32_t outer_idx = 0) {
     RT_PROF(unsigned long long t0 = __builtin_readcyclecounter(); prof.rounds++;)
     // with few rays in the wave (the last rays of a pass) a fixed quorum is never met and every round would advance each
     // ray by a single step: ask for half of the lanes that hold a ray instead
@@ -908,7 +918,7 @@ __device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Wal
     bool done = false;
     RT_PROF(if (__any(special)) prof.specials++;)
     n_box += (uint32_t)__popcll(__ballot(special && (kind == rt::ENT_INNER_INV || kind == rt::ENT_INNER)));   // boxes tested as written
-    if (special) done = walker_special(sc, st, w);
+    if (special) done = walker_special<RELOAD>(sc, st, w, outer_a, outer_b, outer_idx);
     RT_PROF(prof.special += __builtin_readcyclecounter() - t2;)
     return done;
 }

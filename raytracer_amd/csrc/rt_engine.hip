@@ -259,7 +259,6 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, C
     const uint32_t n_stripes = (n_in + STRIPE - 1) / STRIPE;
     uint32_t range = blockIdx.x % NCUR;
     const int lane = (int)(threadIdx.x & 63u);
-    const unsigned long long below = (1ull << lane) - 1ull;
     Walker w;
     walker_idle(sc, w);
     uint32_t my_idx = 0;
@@ -312,7 +311,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, C
             }
             if (mine == mine_end) drained = true;
             else {
-                const uint32_t o = mine + (uint32_t)__popcll(idle & below);
+                const uint32_t o = mine + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));   // idle lanes below this one
                 const uint32_t idx = ((o / STRIPE) * NCUR + mine_range) * STRIPE + o % STRIPE;
                 if (FIRST) {
                     // camera, frame and batch records: read here, not kept in registers between refills
@@ -343,7 +342,13 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, C
             if (drained) break;
             continue;
         }
-        if (walk_round<STAGED, FOG>(sc, st, w, tune.quorum, tune.prim_quorum, tune.finish_quorum, prof, n_box)) {
+        // bounce passes of scenes read from memory: a lane inside an instance does not keep the ray as given, it reads it
+        // again from the queue on the way out (97 registers instead of 110).  Not with the scene in LDS: there the blocks
+        // are bounded by LDS, and reading the ray again cost 0.3 ms of a C2 frame.  (A fifth wave per SIMD, which 96
+        // registers allow, was measured on both kinds of scene and gained nothing: 256-thread blocks on the
+        // 100 000-primitive scene 92.9 against 92.3 ms; 640-thread blocks with the scene in LDS lose a fifth,
+        // their ten waves do not spread evenly over four SIMDs.)
+        if (walk_round<STAGED, FOG, !FIRST && !STAGED>(sc, st, w, tune.quorum, tune.prim_quorum, tune.finish_quorum, prof, n_box, q.a[qin], q.b[qin], my_idx)) {
             q.hit[my_idx] = make_float4(w.c.dist, __int_as_float(w.c.best), w.c.u, w.c.v);
             if (FOG) q.hit_ctr[my_idx] = w.rng.ctr;
         }
@@ -749,10 +754,6 @@ void launch_intersect(rt_engine* e, hipStream_t st, const Cfg& g, const Batch& b
     if (!e->staged_bytes) tune.quorum = e->quorum_mem;
 #define RT_LAUNCH_INTERSECT(STAGED, FOG, LDS_BYTES) \
     hipLaunchKernelGGL((intersect_kernel<FIRST, STAGED, FOG>), dim3(blocks), dim3(IBLOCK), LDS_BYTES, st, e->sc, e->cam, g, bt, q, pass, e->dbg, tune)
-    if (e->staged_bytes && !fog && !FIRST && getenv("RT_BLOCK640")) {
-        hipLaunchKernelGGL((intersect_kernel<false, true, false, 640, 5>), dim3(blocks), dim3(640), e->staged_bytes, st, e->sc, e->cam, g, bt, q, pass, e->dbg, tune);
-        return;
-    }
     if (e->staged_bytes) { if (fog) RT_LAUNCH_INTERSECT(true, true, e->staged_bytes); else RT_LAUNCH_INTERSECT(true, false, e->staged_bytes); }
     else { if (fog) RT_LAUNCH_INTERSECT(false, true, 0); else RT_LAUNCH_INTERSECT(false, false, 0); }
 #undef RT_LAUNCH_INTERSECT
@@ -870,7 +871,6 @@ int init_engine(rt_engine* e, const rt_config* cfg) {
     // not of an engine or a scene, so every engine sets the same value
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<false, true, false, 640, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
 #ifdef RT_PROFILE
@@ -1030,7 +1030,7 @@ static int rt_engine_set_scene_impl(rt_engine* e, const rt_scene* s) {
     e->sc = sc;
     // stage the whole scene in LDS when two 512-thread blocks per CU can each hold it (160 KiB per CU)
     const size_t need = (inter.size() + f->tris.size() + f->inst.size() + f->planes.size()) * 16;
-    e->staged_bytes = need <= (size_t)MAX_STAGED_BYTES ? need : 0;
+    e->staged_bytes = (need <= (size_t)MAX_STAGED_BYTES && !(e->cfg.flags & RT_FLAG_NO_LDS)) ? need : 0;
     e->have_scene = true;
     return RT_OK;
 }

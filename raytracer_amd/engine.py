@@ -17,6 +17,7 @@ MAT_NONE, MAT_DIFFUSE, MAT_METAL, MAT_ISOTROPIC, MAT_LIGHT = 0, 1, 2, 3, 4
 TEX_COLOR, TEX_CHECKER, TEX_IMAGE = 0, 1, 2
 TRACE_STATIC_MAX_RAYS = 32768   # RT_TRACE_STATIC_MAX_RAYS
 FLAG_NO_CULL = 1                # RT_FLAG_NO_CULL
+FLAG_NO_LDS = 2                 # RT_FLAG_NO_LDS
 
 f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")

@@ -596,6 +596,17 @@ def test_random_scenes_bit_exact(rt, orc, assets, seed):
     assert_bits(got["rng_draws"], ref["rng_draws"], f"random scene {seed}: RNG draws")
     assert_bits(got["radiance"], ref["radiance"], f"random scene {seed}: radiance")
     assert_bits(frame, ref["rgba"], f"random scene {seed}: frame")
+    # the same scene read from device memory instead of on-chip memory (the kernels of large scenes, here with mesh
+    # instances, rotations and fog in them), with and without distance culling
+    for flags in (rt.engine.FLAG_NO_LDS, rt.engine.FLAG_NO_LDS | rt.engine.FLAG_NO_CULL):
+        m = make_engine(rt, scene, W, H, S, B, cam, flags=flags)
+        m.keep_samples(True)
+        frame_m = m.render_frame(seed)
+        got_m = m.read_samples()
+        for name in ("primary_id", "primary_t", "rng_draws", "radiance"):
+            assert_bits(got_m[name], ref[name], f"random scene {seed} read from memory (flags {flags}): {name}")
+        assert_bits(frame_m, ref["rgba"], f"random scene {seed} read from memory (flags {flags}): frame")
+        m.close()
 
 
 def _culling_stress_rays(obj, rng, n_targets):
