@@ -536,7 +536,10 @@ __device__ __forceinline__ void walker_start(const Scene& sc, const Store& st, W
 //     quotient's rounding; when the largest entry and the smallest exit distance are further apart than 2^-20 of their
 //     magnitude the exactly rounded quotients order the same way (and a quotient's sign is that of its product), so the
 //     decision stands.  Only if some lane is closer than that does the wave compute the exact quotients (the four packed
-//     FMAs per axis) and decide again — a few box tests in a million;
+//     FMAs per axis) and decide again — a few box tests in a million.  "Closer than that" is tested on the bit patterns:
+//     two floats within 2^-20 of their magnitude have the same sign and lie at most 16 representable values apart, so
+//     the difference of their patterns is within [-32, 31] (three integer instructions; distances of either sign that
+//     are both zero need no second look: a zero quotient is exactly zero);
 //   * the loads land in the registers that already hold the entry: nothing is copied (from LDS as tied operands; from
 //     memory the entry is bound to v22..v29, because a 16-byte load needs a register quadruple and the operands are
 //     pairs);
@@ -599,12 +602,11 @@ __device__ __forceinline__ void box_steps(const Store& st, Walker& w, int quorum
                  "v_min3_f32 v3, v3, v5, v7\n\t"
                  "v_cmp_le_f32_e32 vcc, v8, v3\n\t"
                  "v_cmp_nlt_f32_e64 %[m3], v3, 0\n\t"
-                 "v_sub_f32_e32 v9, v3, v8\n\t"
-                 "v_max_f32_e64 v2, |v8|, |v3|\n\t"
+                 "v_sub_u32_e32 v9, v3, v8\n\t"
                  "s_and_b64 vcc, vcc, %[m3]\n\t"
-                 "v_mul_f32_e32 v2, 0x35800000, v2\n\t"
+                 "v_add_u32_e32 v9, 32, v9\n\t"
                  "v_add_u32_e32 v4, 1, %[i]\n\t"
-                 "v_cmp_le_f32_e64 %[m3], |v9|, v2\n\t"
+                 "v_cmp_gt_u32_e64 %[m3], 64, v9\n\t"
                  "s_cmp_eq_u64 %[m3], 0\n\t"
                  "s_cbranch_scc1 5f\n\t"
                  "v_pk_mul_f32 v[2:3], v[10:11], %[p1] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
@@ -705,12 +707,11 @@ __device__ __forceinline__ void box_steps(const Store& st, Walker& w, int quorum
                  "v_cmp_le_f32_e32 vcc, v8, v3\n\t"
                  "v_cmp_nlt_f32_e64 %[m3], v3, 0\n\t"
                  "v_cmp_ngt_f32_e64 %[m4], v8, v5\n\t"
-                 "v_sub_f32_e32 v9, v3, v8\n\t"
-                 "v_max_f32_e64 v2, |v8|, |v3|\n\t"
+                 "v_sub_u32_e32 v9, v3, v8\n\t"
                  "s_and_b64 vcc, vcc, %[m3]\n\t"
-                 "v_mul_f32_e32 v2, 0x35800000, v2\n\t"
+                 "v_add_u32_e32 v9, 32, v9\n\t"
                  "v_add_u32_e32 v4, 1, %[i]\n\t"
-                 "v_cmp_le_f32_e64 %[m3], |v9|, v2\n\t"
+                 "v_cmp_gt_u32_e64 %[m3], 64, v9\n\t"
                  "s_cmp_eq_u64 %[m3], 0\n\t"
                  "s_cbranch_scc1 5f\n\t"
                  "v_pk_mul_f32 v[2:3], v[10:11], %[p1] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
