@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Throughput with K frames in flight on one GPU: K engines (own stream and queues each) take the frames of a sequence in
-turn, nobody waits between frames.   python tools/frames_in_flight.py [n_ranks]   (rank 0's share of the C2 frame)"""
+turn, nobody waits between frames.   python tools/frames_in_flight.py [n_ranks [k ...]]   (rank 0's share of the C2 frame)"""
 import os
 import sys
 import time
@@ -13,7 +13,7 @@ n_ranks = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 W, H, S, B = 1920, 1080, 8, 8
 scene = rt.default_scene(0x5EED0001)
 cam = rt.camera_look((0.0, 3.0, -10.0), (0.0, 0.0, 1.0))
-for k in (1, 2, 3, 1):
+for k in [int(a) for a in sys.argv[2:]] or [1, 2, 3, 1]:
     engs, bufs = [], []
     for _ in range(k):
         e = rt.Engine(rt.default_config(width=W, height=H, samples_per_axis=S, bounces=B))
