@@ -243,6 +243,7 @@ __device__ __forceinline__ T kernarg_read(size_t offset) {
 }
 
 // ---- intersect (World.cpp:105-119) ----------------------------------------------------------------------------------
+// (the parameter list is mirrored by IntersectArgs, through which kernarg_read finds cam, g and bt: change both together)
 template <bool FIRST, bool STAGED, bool FOG, int BLOCK = IBLOCK, int MIN_WAVES = 1>
 __global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, Cam cam, Cfg g, Batch bt, Queues q, int pass, Debug dbg, Tune tune) {
     extern __shared__ float4 smem[];
@@ -415,6 +416,7 @@ __device__ __forceinline__ bool shade_ray(const Scene& sc, const Cfg& g, const B
 }
 
 // ---- shade + compact (World.cpp:121-170) ------------------------------------------------------------------------------
+// (the parameter list begins like IntersectArgs, through which kernarg_read finds cam, g and bt: change both together)
 template <bool FIRST>
 __global__ __launch_bounds__(256) void shade_kernel(Scene sc, Cam cam, Cfg g, Batch bt, Queues q, int pass, Debug dbg) {
     // A block shades STILE consecutive queue positions per round and collects the surviving rays in LDS; one global
