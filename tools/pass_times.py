@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Per-kernel time of the C2 frame from HIP events is not split by kernel; this prints frame time and the intersect share:
-python tools/pass_times.py   (frame ms, intersect ms: the rest is shading and the resolve)"""
+"""C2 frame time and the part of it spent in the intersect kernels (HIP events around those launches; the rest is shading
+and the resolve):   python tools/pass_times.py     (RT_ENGINE_LIB=<other build> for A/B runs on one box)"""
 import os
 import sys
 import time
