@@ -337,6 +337,7 @@ def run_workload(job, rt, workload, steps, warmup, batch_paths=0, in_flight=1):
     eng.time_kernels(True)
     t0 = time.perf_counter()
     if workload == "c5":
+        host_frame = None
         for f in range(steps):
             cam = rt.camera_input(cam, 3.0, 1.0, w=int(f % 240 < 120), d=int(f % 240 >= 120))
             eng.set_camera(cam)
@@ -350,7 +351,10 @@ def run_workload(job, rt, workload, steps, warmup, batch_paths=0, in_flight=1):
                 frame = tr.render_frame(SEED + f)
                 job.barrier()
                 if frame is not None:
-                    frame.cpu()
+                    if host_frame is None:       # page-locked, as the one-GPU path's rt_engine_map_frame buffer is
+                        host_frame = job.torch.empty(frame.numel(), dtype=frame.dtype, pin_memory=True)
+                    host_frame.copy_(frame, non_blocking=True)
+                    job.torch.cuda.synchronize(job.device)
             frame_ms.append((time.perf_counter() - t1) * 1e3)
     else:
         for _ in range(steps):
