@@ -44,6 +44,7 @@ static __device__ __align__(256) unsigned char scratch[(size_t)RT_TRACE_STATIC_M
 namespace {
 
 constexpr int IBLOCK = 512;         // intersect: 8 waves per block; two blocks per CU, each with its own copy of the scene in LDS
+constexpr long long WIDE_MIN_PATHS = 1ll << 26;   // batches of at least this many paths run their bounce passes with 768-thread blocks
 constexpr int MAX_STAGED_BYTES = 80 * 1024;   // largest scene copy a block keeps in LDS (two blocks share a CU's 160 KiB)
 // Reservation counters of the intersect passes: the queue of a pass is cut into NCUR ranges with a counter each (a single
 // counter would take every reservation of the grid, and additions to one address are served one after another); the
@@ -345,11 +346,12 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, C
         }
         // bounce passes of scenes read from memory: a lane inside an instance does not keep the ray as given, it reads it
         // again from the queue on the way out (97 registers instead of 110).  Not with the scene in LDS: there the blocks
-        // are bounded by LDS, and reading the ray again cost 0.3 ms of a C2 frame.  (A fifth wave per SIMD, which 96
+        // are bounded by LDS, and reading the ray again cost 0.3 ms of a C2 frame — except in the 768-thread variant
+        // (launch_intersect), which needs the registers for its sixth wave per SIMD.  (A fifth wave per SIMD, which 96
         // registers allow, was measured on both kinds of scene and gained nothing: 256-thread blocks on the
         // 100 000-primitive scene 92.9 against 92.3 ms; 640-thread blocks with the scene in LDS lose a fifth,
         // their ten waves do not spread evenly over four SIMDs.)
-        if (walk_round<STAGED, FOG, !FIRST && !STAGED>(sc, st, w, tune.quorum, tune.prim_quorum, tune.finish_quorum, prof, n_box, q.a[qin], q.b[qin], my_idx)) {
+        if (walk_round<STAGED, FOG, !FIRST && (!STAGED || BLOCK != IBLOCK)>(sc, st, w, tune.quorum, tune.prim_quorum, tune.finish_quorum, prof, n_box, q.a[qin], q.b[qin], my_idx)) {
             q.hit[my_idx] = make_float4(w.c.dist, __int_as_float(w.c.best), w.c.u, w.c.v);
             if (FOG) q.hit_ctr[my_idx] = w.rng.ctr;
         }
@@ -679,6 +681,8 @@ struct rt_engine {
     int n_cus = 0;
     Tune tune{32, 16, 8, 256, 16, 64, 16, 1};
     int quorum_mem = 24;                // Tune::quorum for scenes read from memory (RT_QUORUM sets both)
+    int wide_blocks = -1;               // 768-thread bounce passes: -1 by batch size, 0 never, 1 always (RT_WIDE_BLOCKS)
+    int wide_max_pass = 3;              // ... up to this bounce (later passes hold a few per cent of the paths: 17.45 -> 17.35 ms)
     int win[4] = {0, 0, 0, 0};          // x0, y0, width, height of the render window
     // statistics of the last render
     std::vector<uint32_t> h_counts;     // per batch: counts (B + 2), cursors (B + 2)
@@ -756,6 +760,15 @@ void launch_intersect(rt_engine* e, hipStream_t st, const Cfg& g, const Batch& b
     if (!e->staged_bytes) tune.quorum = e->quorum_mem;
 #define RT_LAUNCH_INTERSECT(STAGED, FOG, LDS_BYTES) \
     hipLaunchKernelGGL((intersect_kernel<FIRST, STAGED, FOG>), dim3(blocks), dim3(IBLOCK), LDS_BYTES, st, e->sc, e->cam, g, bt, q, pass, e->dbg, tune)
+    // Large bounce passes over a scene in LDS: 768-thread blocks, twelve waves that spread evenly over the four SIMDs, two
+    // blocks per CU as before: six waves per SIMD instead of four (80 registers).  Measured on the 1920 x 1080 x 64 spp
+    // frame: 18.0 -> 17.5 ms in the intersect kernels.  Small passes lose with larger blocks (more waves wait at the end:
+    // an eighth of that frame 4.94 -> 5.1 ms), so the shape follows the size of the batch and the depth of the pass.
+    const bool wide = e->wide_blocks < 0 ? (long long)bt.n_pixels * (g.S * g.S) >= WIDE_MIN_PATHS : e->wide_blocks != 0;
+    if (e->staged_bytes && !fog && !FIRST && wide && pass <= e->wide_max_pass) {
+        hipLaunchKernelGGL((intersect_kernel<false, true, false, 768, 6>), dim3(blocks), dim3(768), e->staged_bytes, st, e->sc, e->cam, g, bt, q, pass, e->dbg, tune);
+        return;
+    }
     if (e->staged_bytes) { if (fog) RT_LAUNCH_INTERSECT(true, true, e->staged_bytes); else RT_LAUNCH_INTERSECT(true, false, e->staged_bytes); }
     else { if (fog) RT_LAUNCH_INTERSECT(false, true, 0); else RT_LAUNCH_INTERSECT(false, false, 0); }
 #undef RT_LAUNCH_INTERSECT
@@ -873,6 +886,7 @@ int init_engine(rt_engine* e, const rt_config* cfg) {
     // not of an engine or a scene, so every engine sets the same value
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<false, true, false, 768, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
 #ifdef RT_PROFILE
@@ -886,6 +900,8 @@ int init_engine(rt_engine* e, const rt_config* cfg) {
     if (const char* v = getenv("RT_MIN_CHUNK")) e->tune.min_chunk = std::max(8, atoi(v) & ~7);
     if (const char* v = getenv("RT_GUIDE")) e->tune.guide = std::max(1, std::min(64, atoi(v)));
     if (const char* v = getenv("RT_FINISH_QUORUM")) e->tune.finish_quorum = std::max(1, std::min(65, atoi(v)));
+    if (const char* v = getenv("RT_WIDE_BLOCKS")) e->wide_blocks = atoi(v) ? 1 : 0;
+    if (const char* v = getenv("RT_WIDE_MAX_PASS")) e->wide_max_pass = atoi(v);
     if (const char* v = getenv("RT_PRIM_QUORUM")) e->tune.prim_quorum = std::max(1, std::min(65, atoi(v)));
     return RT_OK;
 }

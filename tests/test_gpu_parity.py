@@ -321,7 +321,7 @@ def test_batching_tiles_and_ranks_do_not_change_pixels(rt, gpu_default):
         assert_bits(out.cpu().numpy().reshape(H, W, 4), base, f"{n_ranks}-rank tile split")
 
 
-def test_c2_full_frame_properties(rt, gpu_default):
+def test_c2_full_frame_properties(rt, gpu_default, monkeypatch):
     """BASELINE's full size (1920x1080, 64 spp, 8 bounces): deterministic, alpha constant, windows agree with the frame"""
     W, H, S, B = 1920, 1080, 8, 8
     e = make_engine(rt, gpu_default, W, H, S, B)
@@ -337,6 +337,11 @@ def test_c2_full_frame_properties(rt, gpu_default):
     c = e2.render_frame(7)
     assert_bits(c[508:540, 928:992], a[508:540, 928:992], "window vs full frame")
     assert not c[:508].any()
+    # a batch of this size runs its first bounce passes with 768-thread blocks; the same frame with 512-thread blocks
+    monkeypatch.setenv("RT_WIDE_BLOCKS", "0")
+    e3 = make_engine(rt, gpu_default, W, H, S, B)
+    monkeypatch.delenv("RT_WIDE_BLOCKS")
+    assert_bits(e3.render_frame(7), a, "512-thread against 768-thread bounce passes")
 
 
 def test_error_behaviour(rt, gpu_default):
@@ -576,7 +581,7 @@ def test_degenerate_scenes_and_sizes(rt, orc, assets, case):
 
 
 @pytest.mark.parametrize("seed", [101, 202, 303, 404, 505, 606, 707, 808])
-def test_random_scenes_bit_exact(rt, orc, assets, seed):
+def test_random_scenes_bit_exact(rt, orc, assets, seed, monkeypatch):
     """scenes nobody arranged: ids, distances, draw counts, radiance and frame bytes against the oracle, bit for bit"""
     tex, mat, obj, plane, (pos, look) = random_tables(seed)
     args = (tex, mat, obj, plane, assets["verts"], assets["tex"], assets["sky"], 0xC0FFEE + seed)
@@ -598,7 +603,9 @@ def test_random_scenes_bit_exact(rt, orc, assets, seed):
     assert_bits(frame, ref["rgba"], f"random scene {seed}: frame")
     # the same scene read from device memory instead of on-chip memory (the kernels of large scenes, here with mesh
     # instances, rotations and fog in them), with and without distance culling
-    for flags in (rt.engine.FLAG_NO_LDS, rt.engine.FLAG_NO_LDS | rt.engine.FLAG_NO_CULL):
+    # ... and from on-chip memory with the 768-thread blocks that large batches use for their first bounce passes
+    monkeypatch.setenv("RT_WIDE_BLOCKS", "1")
+    for flags in (rt.engine.FLAG_NO_LDS, rt.engine.FLAG_NO_LDS | rt.engine.FLAG_NO_CULL, 0):
         m = make_engine(rt, scene, W, H, S, B, cam, flags=flags)
         m.keep_samples(True)
         frame_m = m.render_frame(seed)
