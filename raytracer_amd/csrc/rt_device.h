@@ -545,7 +545,9 @@ __device__ __forceinline__ void walker_start(const Scene& sc, const Store& st, W
 //     pairs);
 //   * the lanes that act are enabled through exec inside the block (restored before every test and at the end), so the
 //     surrounding control flow is wave-uniform.
-// v2..v21 are used as scratch registers by name because the halves of a register pair cannot be named through operands.
+// v2..v15 are used as scratch registers by name because the halves of a register pair cannot be named through operands;
+// the exact quotients' residuals go into the registers of the entry itself, which the box step has consumed by then and
+// the fetch at the end of the iteration overwrites for every lane that stepped.
 // Every lane of the wave must be enabled at the call.
 // RT_PROFILE builds (make PROF=1) time the phases of every round with the shader clock; see intersect_kernel
 struct Prof { unsigned long long box = 0, prim = 0, special = 0, refill = 0; unsigned rounds = 0, prims = 0, prim_lanes = 0, specials = 0, box_iters = 0, box_lanes = 0, finishes = 0, finish_lanes = 0; };
@@ -589,56 +591,59 @@ __device__ __forceinline__ void box_steps(const Store& st, Walker& w, int quorum
                  "v_pk_add_f32 v[10:11], %[e01], %[p0] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
                  "v_pk_add_f32 v[12:13], %[e23], %[p0] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
                  "v_pk_add_f32 v[14:15], %[e45], %[p1] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
-                 "v_pk_mul_f32 v[2:3], v[10:11], %[p1] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
-                 "v_pk_mul_f32 v[4:5], v[12:13], %[p2] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
-                 "v_pk_mul_f32 v[6:7], v[14:15], %[p2] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
-                 "v_cndmask_b32_e64 v8, v3, v2, %[px]\n\t"
-                 "v_cndmask_b32_e64 v3, v2, v3, %[px]\n\t"
-                 "v_cndmask_b32_e64 v2, v5, v4, %[py]\n\t"
-                 "v_cndmask_b32_e64 v5, v4, v5, %[py]\n\t"
-                 "v_cndmask_b32_e64 v4, v7, v6, %[pz]\n\t"
-                 "v_cndmask_b32_e64 v7, v6, v7, %[pz]\n\t"
-                 "v_max3_f32 v8, v8, v2, v4\n\t"
-                 "v_min3_f32 v3, v3, v5, v7\n\t"
-                 "v_cmp_le_f32_e32 vcc, v8, v3\n\t"
-                 "v_cmp_nlt_f32_e64 %[m3], v3, 0\n\t"
-                 "v_sub_u32_e32 v9, v3, v8\n\t"
+                 "v_pk_mul_f32 v[10:11], v[10:11], %[p1] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                 "v_pk_mul_f32 v[12:13], v[12:13], %[p2] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+                 "v_pk_mul_f32 v[14:15], v[14:15], %[p2] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                 "v_cndmask_b32_e64 v8, v11, v10, %[px]\n\t"
+                 "v_cndmask_b32_e64 v11, v10, v11, %[px]\n\t"
+                 "v_cndmask_b32_e64 v10, v13, v12, %[py]\n\t"
+                 "v_cndmask_b32_e64 v13, v12, v13, %[py]\n\t"
+                 "v_cndmask_b32_e64 v12, v15, v14, %[pz]\n\t"
+                 "v_cndmask_b32_e64 v15, v14, v15, %[pz]\n\t"
+                 "v_max3_f32 v8, v8, v10, v12\n\t"
+                 "v_min3_f32 v11, v11, v13, v15\n\t"
+                 "v_cmp_le_f32_e32 vcc, v8, v11\n\t"
+                 "v_cmp_nlt_f32_e64 %[m3], v11, 0\n\t"
+                 "v_sub_u32_e32 v9, v11, v8\n\t"
                  "s_and_b64 vcc, vcc, %[m3]\n\t"
                  "v_add_u32_e32 v9, 32, v9\n\t"
-                 "v_add_u32_e32 v4, 1, %[i]\n\t"
+                 "v_add_u32_e32 v10, 1, %[i]\n\t"
                  "v_cmp_gt_u32_e64 %[m3], 64, v9\n\t"
                  "s_cmp_eq_u64 %[m3], 0\n\t"
                  "s_cbranch_scc1 5f\n\t"
-                 "v_pk_mul_f32 v[2:3], v[10:11], %[p1] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
-                 "v_pk_mul_f32 v[4:5], v[12:13], %[p2] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
-                 "v_pk_mul_f32 v[6:7], v[14:15], %[p2] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
-                 "v_pk_fma_f32 v[16:17], %[p3], v[2:3], v[10:11] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 v[18:19], %[p3], v[4:5], v[12:13] op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 v[20:21], %[p4], v[6:7], v[14:15] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 v[2:3], v[16:17], %[p1], v[2:3] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                 "v_pk_fma_f32 v[4:5], v[18:19], %[p2], v[4:5] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
-                 "v_pk_fma_f32 v[6:7], v[20:21], %[p2], v[6:7] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                 "v_pk_fma_f32 v[16:17], %[p3], v[2:3], v[10:11] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 v[18:19], %[p3], v[4:5], v[12:13] op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 v[20:21], %[p4], v[6:7], v[14:15] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 v[2:3], v[16:17], %[p1], v[2:3] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                 "v_pk_fma_f32 v[4:5], v[18:19], %[p2], v[4:5] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
-                 "v_pk_fma_f32 v[6:7], v[20:21], %[p2], v[6:7] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                 "v_cndmask_b32_e64 v8, v3, v2, %[px]\n\t"
-                 "v_cndmask_b32_e64 v3, v2, v3, %[px]\n\t"
-                 "v_cndmask_b32_e64 v2, v5, v4, %[py]\n\t"
-                 "v_cndmask_b32_e64 v5, v4, v5, %[py]\n\t"
-                 "v_cndmask_b32_e64 v4, v7, v6, %[pz]\n\t"
-                 "v_cndmask_b32_e64 v7, v6, v7, %[pz]\n\t"
-                 "v_max3_f32 v8, v8, v2, v4\n\t"
-                 "v_min3_f32 v3, v3, v5, v7\n\t"
-                 "v_cmp_le_f32_e32 vcc, v8, v3\n\t"
-                 "v_cmp_nlt_f32_e64 %[m3], v3, 0\n\t"
-                 "v_add_u32_e32 v4, 1, %[i]\n\t"
+                 "v_pk_add_f32 v[10:11], %[e01], %[p0] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                 "v_pk_mul_f32 v[12:13], v[10:11], %[p1] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                 "v_pk_fma_f32 %[e01], %[p3], v[12:13], v[10:11] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[12:13], %[e01], %[p1], v[12:13] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 %[e01], %[p3], v[12:13], v[10:11] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[14:15], %[e01], %[p1], v[12:13] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_add_f32 v[10:11], %[e23], %[p0] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                 "v_pk_mul_f32 v[12:13], v[10:11], %[p2] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+                 "v_pk_fma_f32 %[e23], %[p3], v[12:13], v[10:11] op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[12:13], %[e23], %[p2], v[12:13] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 %[e23], %[p3], v[12:13], v[10:11] op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[10:11], %[e23], %[p2], v[12:13] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_add_f32 %[e01], %[e45], %[p1] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+                 "v_pk_mul_f32 v[12:13], %[e01], %[p2] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+                 "v_pk_fma_f32 %[e45], %[p4], v[12:13], %[e01] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[12:13], %[e45], %[p2], v[12:13] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 %[e45], %[p4], v[12:13], %[e01] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[12:13], %[e45], %[p2], v[12:13] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_cndmask_b32_e64 v8, v15, v14, %[px]\n\t"
+                 "v_cndmask_b32_e64 v15, v14, v15, %[px]\n\t"
+                 "v_cndmask_b32_e64 v14, v11, v10, %[py]\n\t"
+                 "v_cndmask_b32_e64 v11, v10, v11, %[py]\n\t"
+                 "v_cndmask_b32_e64 v10, v13, v12, %[pz]\n\t"
+                 "v_cndmask_b32_e64 v13, v12, v13, %[pz]\n\t"
+                 "v_max3_f32 v8, v8, v14, v10\n\t"
+                 "v_min3_f32 v11, v15, v11, v13\n\t"
+                 "v_cmp_le_f32_e32 vcc, v8, v11\n\t"
+                 "v_cmp_nlt_f32_e64 %[m3], v11, 0\n\t"
+                 "v_add_u32_e32 v10, 1, %[i]\n\t"
                  "s_and_b64 vcc, vcc, %[m3]\n\t"
                  "5:\n\t"
                  "s_nop 0\n\t"
-                 "v_cndmask_b32_e32 %[i], %[sk], v4, vcc\n\t"
+                 "v_cndmask_b32_e32 %[i], %[sk], v10, vcc\n\t"
                  "3:\n\t"
                  "s_cmp_eq_u64 %[m2], 0\n\t"
                  "s_cbranch_scc1 4f\n\t"
@@ -653,11 +658,11 @@ __device__ __forceinline__ void box_steps(const Store& st, Walker& w, int quorum
                  "4:\n\t"
                  "s_and_b64 exec, %[saved], %[mall]\n\t"
                  RT_BOX_COUNT
-                 "v_lshl_add_u32 v2, %[i], 5, %[base]\n\t"
-                 "ds_read_b64 %[e01], v2\n\t"
-                 "ds_read_b64 %[e23], v2 offset:8\n\t"
-                 "ds_read_b64 %[e45], v2 offset:16\n\t"
-                 "ds_read_b32 %[sk], v2 offset:24\n\t"
+                 "v_lshl_add_u32 v8, %[i], 5, %[base]\n\t"
+                 "ds_read_b64 %[e01], v8\n\t"
+                 "ds_read_b64 %[e23], v8 offset:8\n\t"
+                 "ds_read_b64 %[e45], v8 offset:16\n\t"
+                 "ds_read_b32 %[sk], v8 offset:24\n\t"
                  "s_waitcnt lgkmcnt(0)\n\t"
                  "s_mov_b64 exec, %[saved]\n\t"
                  "s_bcnt1_i32_b64 %[cntS], %[m]\n\t"
@@ -670,8 +675,7 @@ __device__ __forceinline__ void box_steps(const Store& st, Walker& w, int quorum
                    [mall] "=&s"(mall), [saved] "=&s"(saved), [cntS] "=&s"(n_inner), [nbox] "+s"(nb) RT_BOX_COUNT_OPERANDS
                  : [p0] "v"(w.p0), [p1] "v"(w.p1), [p2] "v"(w.p2), [p3] "v"(w.p3), [p4] "v"(w.p4), [px] "s"(px), [py] "s"(py),
                    [pz] "s"(pz), [base] "s"(base), [usable] "s"(usable), [quorum] "s"(quorum)
-                 : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18",
-                   "v19", "v20", "v21", "vcc", "scc", "memory");
+                 : "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "vcc", "scc", "memory");
     } else {
         const float4* base = st.ent;
         asm volatile(
@@ -717,18 +721,18 @@ __device__ __forceinline__ void box_steps(const Store& st, Walker& w, int quorum
                  "v_pk_mul_f32 v[2:3], v[10:11], %[p1] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
                  "v_pk_mul_f32 v[4:5], v[12:13], %[p2] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
                  "v_pk_mul_f32 v[6:7], v[14:15], %[p2] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
-                 "v_pk_fma_f32 v[16:17], %[p3], v[2:3], v[10:11] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 v[18:19], %[p3], v[4:5], v[12:13] op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 v[20:21], %[p4], v[6:7], v[14:15] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 v[2:3], v[16:17], %[p1], v[2:3] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                 "v_pk_fma_f32 v[4:5], v[18:19], %[p2], v[4:5] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
-                 "v_pk_fma_f32 v[6:7], v[20:21], %[p2], v[6:7] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                 "v_pk_fma_f32 v[16:17], %[p3], v[2:3], v[10:11] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 v[18:19], %[p3], v[4:5], v[12:13] op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 v[20:21], %[p4], v[6:7], v[14:15] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
-                 "v_pk_fma_f32 v[2:3], v[16:17], %[p1], v[2:3] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
-                 "v_pk_fma_f32 v[4:5], v[18:19], %[p2], v[4:5] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
-                 "v_pk_fma_f32 v[6:7], v[20:21], %[p2], v[6:7] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 %[e01], %[p3], v[2:3], v[10:11] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 %[e23], %[p3], v[4:5], v[12:13] op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 %[e45], %[p4], v[6:7], v[14:15] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[2:3], %[e01], %[p1], v[2:3] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 v[4:5], %[e23], %[p2], v[4:5] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 v[6:7], %[e45], %[p2], v[6:7] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 %[e01], %[p3], v[2:3], v[10:11] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 %[e23], %[p3], v[4:5], v[12:13] op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 %[e45], %[p4], v[6:7], v[14:15] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+                 "v_pk_fma_f32 v[2:3], %[e01], %[p1], v[2:3] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+                 "v_pk_fma_f32 v[4:5], %[e23], %[p2], v[4:5] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+                 "v_pk_fma_f32 v[6:7], %[e45], %[p2], v[6:7] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
                  "v_cndmask_b32_e64 v8, v3, v2, %[px]\n\t"
                  "v_cndmask_b32_e64 v3, v2, v3, %[px]\n\t"
                  "v_cndmask_b32_e64 v2, v5, v4, %[py]\n\t"
@@ -774,27 +778,35 @@ __device__ __forceinline__ void box_steps(const Store& st, Walker& w, int quorum
                    [mall] "=&s"(mall), [saved] "=&s"(saved), [cntS] "=&s"(n_inner), [m4] "=&s"(m4), [rho] "+{v29}"(w.rho), [nbox] "+s"(nb) RT_BOX_COUNT_OPERANDS
                  : [p0] "v"(w.p0), [p1] "v"(w.p1), [p2] "v"(w.p2), [p3] "v"(w.p3), [p4] "v"(w.p4), [px] "s"(px), [py] "s"(py),
                    [pz] "s"(pz), [base] "s"(base), [usable] "s"(usable), [quorum] "s"(quorum), [ck] "v"(w.cull_k), [cbase] "v"(w.cull_base)
-                 : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "v16", "v17", "v18",
-                   "v19", "v20", "v21", "vcc", "scc", "memory");
+                 : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "vcc", "scc", "memory");
     }
     n_box += nb;
     RT_PROF(prof.box_iters += box_iters; prof.box_lanes += box_lanes;)
 }
 
+// The lane's number within its wave, computed where it is asked for (two instructions) instead of being held in a
+// register through the kernel; volatile so that the compiler does not compute it once and keep it.
+__device__ __forceinline__ uint32_t lane_now() {
+    uint32_t l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 // The oldest noted leaf of the lane: Sphere / AxisAlignedCube / Triangle ::Intersect and the closest-hit bookkeeping of
 // BVH_Node::Intersect (Object.cpp:245-251) and World::GetRayColor (World.cpp:110-118).  A triangle the ray reaches stays
 // at the head of the FIFO with its distance in `reach` when the rest of its test can matter — the distance would win, or
 // the leaf is the one whose assignment of HitInfo.distance survives a rejection — and is finished by tri_finish_step.
+// uv_out: where a winning triangle's barycentrics go instead of the lane's registers (the second half of the ray's hit
+// record; the last triangle to win is the last to write, and no other kind of hit reads them).
 template <bool CULL>
-__device__ __forceinline__ void closest_update(const Scene& sc, Walker& w, int e, bool ok, bool wrote, float t, float u, float v) {
+__device__ __forceinline__ void closest_update(const Scene& sc, Walker& w, int e, bool ok, bool wrote, float t, float u, float v, float2* uv_out = nullptr) {
     // selects rather than branches around the updates: the record stays in registers
     const bool better = ok && (!w.c.hit || t < w.c.dist);
     if (CULL && better) cull_update<CULL>(sc, w, t);
     const bool stale = !ok && wrote && e == w.stale;
     w.c.dist = (better || stale) ? t : w.c.dist;
     w.c.best = better ? e : w.c.best;
-    w.c.u = better ? u : w.c.u;
-    w.c.v = better ? v : w.c.v;
+    if (uv_out) { if (better) *uv_out = make_float2(u, v); }
+    else { w.c.u = better ? u : w.c.u; w.c.v = better ? v : w.c.v; }
     w.c.hit = w.c.hit || better;
 }
 template <bool FOG, bool CULL>
@@ -820,29 +832,40 @@ __device__ __forceinline__ void prim_step(const Scene& sc, const Store& st, Walk
     closest_update<CULL>(sc, w, e, ok, wrote, t, 0.0f, 0.0f);
 }
 // The second part of Triangle::Intersect for a lane whose head-of-FIFO triangle is waiting for it.
-template <bool CULL>
-__device__ __forceinline__ void tri_finish_step(const Scene& sc, const Store& st, Walker& w) {
+// LEAN: the alpha mask's place and size are read from the instance record instead of being carried by every lane, and
+// the barycentrics of a winning triangle go straight to the ray's hit record, hit_rec[idx].
+template <bool CULL, bool LEAN = false>
+__device__ __forceinline__ void tri_finish_step(const Scene& sc, const Store& st, Walker& w, float4* hit_rec = nullptr, const uint32_t* idx_slot = nullptr) {
     const int e = (int)w.f0;
     w.f0 = w.f1; w.f1 = w.f2; w.cnt--;
     const uint32_t sk = reinterpret_cast<const uint32_t*>(st.ent)[8 * (size_t)e + 6];
     float t = 0, u = 0, v = 0;
     bool wrote = false;
-    const bool ok = tri_surface(sc, st.tris, sk_payload(sk), w.alpha_off, w.alpha_wh, walker_ray(w), w.reach, t, u, v, wrote);
+    int alpha_off = w.alpha_off;
+    uint32_t alpha_wh = w.alpha_wh;
+    if (LEAN) {
+        const float4 i3 = st.inst[(size_t)w.inst * rt::RT_INST_F4 + 3];
+        alpha_off = __float_as_int(i3.z); alpha_wh = __float_as_uint(i3.w);
+    }
+    const bool ok = tri_surface(sc, st.tris, sk_payload(sk), alpha_off, alpha_wh, walker_ray(w), w.reach, t, u, v, wrote);
     w.reach = 0.0f;
-    closest_update<CULL>(sc, w, e, ok, wrote, t, u, v);
+    closest_update<CULL>(sc, w, e, ok, wrote, t, u, v, LEAN ? reinterpret_cast<float2*>(hit_rec + *idx_slot) + 1 : nullptr);
 }
 // Entries that change the lane's state beyond its position; they wait until every noted leaf has been tested.  Returns
 // true when the ray has finished (closest hit known, plane list merged); the lane is idle from then on.
 // RELOAD: the ray as given is not kept in registers while the lane is inside an instance (ten registers: what decides
 // whether a fifth wave fits a SIMD); on the way out it is read again from the queue record it came from (outer_a,
 // outer_b: the two halves of record `outer_idx`) and its reciprocals are computed again, bit for bit as at the start.
-template <bool RELOAD = false>
+// LEAN: nor are the entry to go on at after the instance and the alpha mask of its texture (three more registers): they
+// are read from the instance record where they are needed.
+template <bool RELOAD = false, bool LEAN = false>
 __device__ __forceinline__ bool walker_special(const Scene& sc, const Store& st, Walker& w, const float4* outer_a = nullptr, const float4* outer_b = nullptr, uint32_t outer_idx = 0) {
     bool done = false;
     const int kind = sk_kind(w.sk);
     if (kind == rt::ENT_END) {
         if (w.inst >= 0) {   // PolygonMesh and its wrappers return to the top level
-            w.i = w.resume; w.inst = -1; w.stale = sc.stale_entry;
+            w.i = LEAN ? __float_as_int(st.inst[(size_t)w.inst * rt::RT_INST_F4 + 2].w) : w.resume;
+            w.inst = -1; w.stale = sc.stale_entry;
             if (RELOAD) {
                 const float4 a = outer_a[outer_idx], b = outer_b[outer_idx];
                 Ray r;
@@ -865,10 +888,10 @@ __device__ __forceinline__ bool walker_special(const Scene& sc, const Store& st,
         const float4 i0 = I[0], i1 = I[1], i2 = I[2], i3 = I[3];
         if (!RELOAD) { w.s0 = w.p0; w.s1 = w.p1; w.s2 = w.p2; w.s3 = w.p3; w.s4 = w.p4; w.s_usable = w.usable; }
         walker_set_ray(w, to_instance(i0, i1, i2, walker_ray(w)), sc.fast_div_ok != 0);
-        w.resume = w.i + 1;
+        if (!LEAN) w.resume = w.i + 1;
         w.stale = (w.i == sc.stale_entry) ? __float_as_int(i3.y) : -1;
         w.inst = ii;
-        w.alpha_off = __float_as_int(i3.z); w.alpha_wh = __float_as_uint(i3.w);   // alpha cut-out of the mesh's texture, or -1
+        if (!LEAN) { w.alpha_off = __float_as_int(i3.z); w.alpha_wh = __float_as_uint(i3.w); }   // alpha cut-out of the mesh's texture, or -1
         w.i = __float_as_int(i2.z);
     } else {
         // an inner entry tested as the reference writes it, with true divisions: a box with min > max on some axis, or
@@ -883,7 +906,7 @@ __device__ __forceinline__ bool walker_special(const Scene& sc, const Store& st,
 // noted leaf; then the state-changing entries of lanes that have none left.  Returns true in lanes whose ray finished.
 template <bool LDS, bool FOG, bool RELOAD = false>
 __device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Walker& w, int quorum, int prim_quorum, int finish_quorum, Prof& prof, uint32_t& n_box,
-                                           const float4* outer_a = nullptr, const float4* outer_b = nullptr, uint32_t outer_idx = 0) {
+                                           const float4* outer_a = nullptr, const float4* outer_b = nullptr, uint32_t outer_idx = 0, float4* hit_rec = nullptr, const uint32_t* idx_slots = nullptr) {
     RT_PROF(unsigned long long t0 = __builtin_readcyclecounter(); prof.rounds++;)
     // with few rays in the wave (the last rays of a pass) a fixed quorum is never met and every round would advance each
     // ray by a single step: ask for half of the lanes that hold a ray instead
@@ -909,7 +932,7 @@ __device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Wal
         const int n = __popcll(__ballot(waiting));
         if (n >= finish_quorum) {
             RT_PROF(prof.finishes++; prof.finish_lanes += n;)
-            if (waiting) tri_finish_step<CULL>(sc, st, w);
+            if (waiting) tri_finish_step<CULL, RELOAD && LDS>(sc, st, w, hit_rec, idx_slots ? idx_slots + lane_now() : nullptr);
         }
     }
     RT_PROF(unsigned long long t2 = __builtin_readcyclecounter(); prof.prim += t2 - t1;)
@@ -919,7 +942,7 @@ __device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Wal
     bool done = false;
     RT_PROF(if (__any(special)) prof.specials++;)
     n_box += (uint32_t)__popcll(__ballot(special && (kind == rt::ENT_INNER_INV || kind == rt::ENT_INNER)));   // boxes tested as written
-    if (special) done = walker_special<RELOAD>(sc, st, w, outer_a, outer_b, outer_idx);
+    if (special) done = walker_special<RELOAD, RELOAD && LDS>(sc, st, w, outer_a, outer_b, idx_slots ? idx_slots[lane_now()] : outer_idx);
     RT_PROF(prof.special += __builtin_readcyclecounter() - t2;)
     return done;
 }

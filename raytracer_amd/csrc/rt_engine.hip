@@ -243,6 +243,10 @@ __device__ __forceinline__ T kernarg_read(size_t offset) {
     return r;
 }
 
+// One dword per thread of the block in LDS, for the kernel variant that is short of registers
+template <int N>
+__device__ __forceinline__ uint32_t* lane_slots() { __shared__ uint32_t slots[N]; return slots; }
+
 // ---- intersect (World.cpp:105-119) ----------------------------------------------------------------------------------
 // (the parameter list is mirrored by IntersectArgs, through which kernarg_read finds cam, g and bt: change both together)
 template <bool FIRST, bool STAGED, bool FOG, int BLOCK = IBLOCK, int MIN_WAVES = 1>
@@ -260,7 +264,10 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, C
     // ((o / STRIPE) * NCUR + r) * STRIPE + o % STRIPE.
     const uint32_t n_stripes = (n_in + STRIPE - 1) / STRIPE;
     uint32_t range = blockIdx.x % NCUR;
-    const int lane = (int)(threadIdx.x & 63u);
+    // RELOAD, LEAN: see walker_special.  The lean variant also keeps the queue position of the lane's ray in LDS.
+    constexpr bool RELOAD = !FIRST && (!STAGED || BLOCK != IBLOCK), LEAN = RELOAD && STAGED;
+    uint32_t* my_slot = nullptr;   // wave-uniform: slot [lane] is this lane's
+    if constexpr (LEAN) my_slot = lane_slots<BLOCK>() + __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u);
     Walker w;
     walker_idle(sc, w);
     uint32_t my_idx = 0;
@@ -284,8 +291,8 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, C
                     const uint32_t size = range_size(n_stripes, range);
                     uint32_t off = 0xFFFFFFFFu;
                     if (size) {
-                        if (lane == 0) off = atomicAdd(q.cursors + range * CUR_STRIDE + pass, chunk);
-                        off = (uint32_t)__shfl((int)off, 0);
+                        if (lane_now() == 0) off = atomicAdd(q.cursors + range * CUR_STRIDE + pass, chunk);
+                        off = __builtin_amdgcn_readfirstlane(off);   // (every lane is enabled here) a scalar: what follows from it stays out of the vector registers
                     }
                     if (off < size) {
                         mine = off;
@@ -299,13 +306,15 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, C
                     }
                     // this range is used up: lane r looks at range r's counter, the wave moves to the range with the most left
                     uint32_t left = 0;
+                    const uint32_t lane = lane_now();
                     if (lane < NCUR) {
-                        const uint32_t sz = range_size(n_stripes, (uint32_t)lane);
+                        const uint32_t sz = range_size(n_stripes, lane);
                         const uint32_t seen = __hip_atomic_load(q.cursors + lane * CUR_STRIDE + pass, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         left = seen < sz ? sz - seen : 0u;
                     }
-                    uint32_t best = left << 6 | (uint32_t)lane;          // left < 2^26: a queue holds fewer than 2^31 positions, a range 1/32 of them
+                    uint32_t best = left << 6 | lane;          // left < 2^26: a queue holds fewer than 2^31 positions, a range 1/32 of them
                     for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)best, d); best = o > best ? o : best; }
+                    best = __builtin_amdgcn_readfirstlane(best);          // the same in every lane by now
                     if ((best >> 6) == 0u) break;                         // nothing left anywhere
                     range = best & 63u;
                     chunk = (uint32_t)tune.min_chunk;
@@ -330,7 +339,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, C
                 } else if (walker_is_idle(w) && o < mine_end && idx < n_in) {
                     Ray ray; Rng rng; uint32_t slot, depth;
                     if (fetch_ray<false>(cam, g, bt, q, qin, dbg, idx, ray, rng, slot, depth, FOG)) {
-                        my_idx = idx;
+                        if constexpr (LEAN) my_slot[lane_now()] = idx; else my_idx = idx;
                         walker_start<CULL>(sc, st, w, ray, rng);
                     }
                 }
@@ -351,14 +360,16 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, C
         // registers allow, was measured on both kinds of scene and gained nothing: 256-thread blocks on the
         // 100 000-primitive scene 92.9 against 92.3 ms; 640-thread blocks with the scene in LDS lose a fifth,
         // their ten waves do not spread evenly over four SIMDs.)
-        if (walk_round<STAGED, FOG, !FIRST && (!STAGED || BLOCK != IBLOCK)>(sc, st, w, tune.quorum, tune.prim_quorum, tune.finish_quorum, prof, n_box, q.a[qin], q.b[qin], my_idx)) {
-            q.hit[my_idx] = make_float4(w.c.dist, __int_as_float(w.c.best), w.c.u, w.c.v);
+        if (walk_round<STAGED, FOG, RELOAD>(sc, st, w, tune.quorum, tune.prim_quorum, tune.finish_quorum, prof, n_box, q.a[qin], q.b[qin], my_idx, q.hit, my_slot)) {
+            // (the lean walker has written the barycentrics of its winning triangle already)
+            if constexpr (LEAN) *reinterpret_cast<float2*>(q.hit + my_slot[lane_now()]) = make_float2(w.c.dist, __int_as_float(w.c.best));
+            else q.hit[my_idx] = make_float4(w.c.dist, __int_as_float(w.c.best), w.c.u, w.c.v);
             if (FOG) q.hit_ctr[my_idx] = w.rng.ctr;
         }
     }
-    if (lane == 0 && n_box) atomicAdd(reinterpret_cast<unsigned long long*>(q.counts + BOX_COUNT_AT) + pass, (unsigned long long)n_box);
+    if (lane_now() == 0 && n_box) atomicAdd(reinterpret_cast<unsigned long long*>(q.counts + BOX_COUNT_AT) + pass, (unsigned long long)n_box);
 #ifdef RT_PROFILE
-    if (dbg.prof && lane == 0 && prof.rounds) {   // per pass: 12 counters summed over the waves that had work
+    if (dbg.prof && lane_now() == 0 && prof.rounds) {   // per pass: 12 counters summed over the waves that had work
         unsigned long long* p = dbg.prof + 16 * (pass < 15 ? pass : 15);
         atomicAdd(p + 0, 1ull); atomicAdd(p + 1, __builtin_readcyclecounter() - t_start); atomicAdd(p + 2, (unsigned long long)prof.rounds);
         atomicAdd(p + 3, prof.box); atomicAdd(p + 4, prof.prim); atomicAdd(p + 5, prof.special); atomicAdd(p + 6, prof.refill);
@@ -764,8 +775,9 @@ void launch_intersect(rt_engine* e, hipStream_t st, const Cfg& g, const Batch& b
     // blocks per CU as before: six waves per SIMD instead of four (80 registers).  Measured on the 1920 x 1080 x 64 spp
     // frame: 18.0 -> 17.5 ms in the intersect kernels.  Small passes lose with larger blocks (more waves wait at the end:
     // an eighth of that frame 4.94 -> 5.1 ms), so the shape follows the size of the batch and the depth of the pass.
+    // The variant keeps one dword per thread in LDS beside the scene (it has no register left for it).
     const bool wide = e->wide_blocks < 0 ? (long long)bt.n_pixels * (g.S * g.S) >= WIDE_MIN_PATHS : e->wide_blocks != 0;
-    if (e->staged_bytes && !fog && !FIRST && wide && pass <= e->wide_max_pass) {
+    if (e->staged_bytes && e->staged_bytes + 768 * sizeof(uint32_t) <= (size_t)MAX_STAGED_BYTES && !fog && !FIRST && wide && pass <= e->wide_max_pass) {
         hipLaunchKernelGGL((intersect_kernel<false, true, false, 768, 6>), dim3(blocks), dim3(768), e->staged_bytes, st, e->sc, e->cam, g, bt, q, pass, e->dbg, tune);
         return;
     }
@@ -1022,6 +1034,13 @@ static int rt_engine_set_scene_impl(rt_engine* e, const rt_scene* s) {
         inst_rec[k + 3].z = rt::bits_f(at);
         inst_rec[k + 3].w = rt::bits_f((int32_t)wh);
     }
+    // ... and the index of the entry behind the instance's own entry in the top-level list, where a ray goes on when it
+    // leaves the instance (in place of the end of the instance's range, which only the host needs)
+    for (int i = 0; i < f->top_end; i++)
+        if (rt::bits_i(f->ent_hi[i].w) == rt::ENT_INSTANCE) {
+            const size_t k = (size_t)rt::bits_i(f->ent_lo[i].x) * rt::RT_INST_F4;
+            if (k + rt::RT_INST_F4 <= inst_rec.size()) inst_rec[k + 2].w = rt::bits_f(i + 1);
+        }
     uint32_t* d_alpha;
     if (int rc = upload(&d_alpha, alpha_bits.data(), alpha_bits.size() * 4)) return rc;
     e->scene_allocs.push_back(d_alpha);

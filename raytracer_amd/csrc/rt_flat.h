@@ -34,6 +34,7 @@
 //   on the device:                    (v0.xyz, v1.x) (v1 - v0, v1.y) (v2 - v0, v1.z) (uv0.xy, uv1.xy) (uv2.xy, n.x, n.y) (n.z, v2.xyz)
 // Instance (RT_INST_F4 = 4):         (offset.xyz, has_move) (pivot.xyz, rot axis or -1) (sin, cos, begin, end)
 //                                    (object id, stale entry, word offset of the texture's alpha bit mask or -1, height << 16 | width)   [the last two: device only]
+//   on the device `end` is replaced by the index of the entry that follows the instance's own entry in the top-level list
 // Object   (RT_OBJ_F4 = 4):          (material type, texture kind, image index, -1 / density of a fog volume) (colour1.rgb, 0) (colour2.rgb, 0) (emit.rgb, 0)
 // Plane    (1):                      (y, object id, 0, 0)
 #pragma once
