@@ -858,8 +858,10 @@ __device__ __forceinline__ void tri_finish_step(const Scene& sc, const Store& st
 // outer_b: the two halves of record `outer_idx`) and its reciprocals are computed again, bit for bit as at the start.
 // LEAN: nor are the entry to go on at after the instance and the alpha mask of its texture (three more registers): they
 // are read from the instance record where they are needed.
-template <bool RELOAD = false, bool LEAN = false>
-__device__ __forceinline__ bool walker_special(const Scene& sc, const Store& st, Walker& w, const float4* outer_a = nullptr, const float4* outer_b = nullptr, uint32_t outer_idx = 0) {
+// SAVE: the ray as given has no queue record (it came from the camera): on the way in it is written to the 32 bytes at
+// outer_a + 2 * outer_idx (one memory sector; outer_b is not used), and read from there on the way out.
+template <bool RELOAD = false, bool LEAN = false, bool SAVE = false>
+__device__ __forceinline__ bool walker_special(const Scene& sc, const Store& st, Walker& w, float4* outer_a = nullptr, float4* outer_b = nullptr, uint32_t outer_idx = 0) {
     bool done = false;
     const int kind = sk_kind(w.sk);
     if (kind == rt::ENT_END) {
@@ -867,7 +869,7 @@ __device__ __forceinline__ bool walker_special(const Scene& sc, const Store& st,
             w.i = LEAN ? __float_as_int(st.inst[(size_t)w.inst * rt::RT_INST_F4 + 2].w) : w.resume;
             w.inst = -1; w.stale = sc.stale_entry;
             if (RELOAD) {
-                const float4 a = outer_a[outer_idx], b = outer_b[outer_idx];
+                const float4 a = SAVE ? outer_a[2 * (size_t)outer_idx] : outer_a[outer_idx], b = SAVE ? outer_a[2 * (size_t)outer_idx + 1] : outer_b[outer_idx];
                 Ray r;
                 r.o = mk(a.x, a.y, a.z); r.d = mk(a.w, b.x, b.y);
                 walker_set_ray(w, r, sc.fast_div_ok != 0);
@@ -887,6 +889,11 @@ __device__ __forceinline__ bool walker_special(const Scene& sc, const Store& st,
         const float4* I = st.inst + (size_t)ii * rt::RT_INST_F4;
         const float4 i0 = I[0], i1 = I[1], i2 = I[2], i3 = I[3];
         if (!RELOAD) { w.s0 = w.p0; w.s1 = w.p1; w.s2 = w.p2; w.s3 = w.p3; w.s4 = w.p4; w.s_usable = w.usable; }
+        if (RELOAD && SAVE) {
+            const Ray r = walker_ray(w);
+            outer_a[2 * (size_t)outer_idx] = make_float4(r.o.x, r.o.y, r.o.z, r.d.x);
+            *reinterpret_cast<float2*>(outer_a + 2 * (size_t)outer_idx + 1) = make_float2(r.d.y, r.d.z);
+        }
         walker_set_ray(w, to_instance(i0, i1, i2, walker_ray(w)), sc.fast_div_ok != 0);
         if (!LEAN) w.resume = w.i + 1;
         w.stale = (w.i == sc.stale_entry) ? __float_as_int(i3.y) : -1;
@@ -904,9 +911,9 @@ __device__ __forceinline__ bool walker_special(const Scene& sc, const Store& st,
 }
 // One round for a wave: the traversal loop; then primitive tests, repeated while at least `prim_quorum` lanes have a
 // noted leaf; then the state-changing entries of lanes that have none left.  Returns true in lanes whose ray finished.
-template <bool LDS, bool FOG, bool RELOAD = false>
+template <bool LDS, bool FOG, bool RELOAD = false, bool SAVE = false>
 __device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Walker& w, int quorum, int prim_quorum, int finish_quorum, Prof& prof, uint32_t& n_box,
-                                           const float4* outer_a = nullptr, const float4* outer_b = nullptr, uint32_t outer_idx = 0, float4* hit_rec = nullptr, const uint32_t* idx_slots = nullptr) {
+                                           float4* outer_a = nullptr, float4* outer_b = nullptr, uint32_t outer_idx = 0, float4* hit_rec = nullptr, const uint32_t* idx_slots = nullptr) {
     RT_PROF(unsigned long long t0 = __builtin_readcyclecounter(); prof.rounds++;)
     // with few rays in the wave (the last rays of a pass) a fixed quorum is never met and every round would advance each
     // ray by a single step: ask for half of the lanes that hold a ray instead
@@ -942,7 +949,7 @@ __device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Wal
     bool done = false;
     RT_PROF(if (__any(special)) prof.specials++;)
     n_box += (uint32_t)__popcll(__ballot(special && (kind == rt::ENT_INNER_INV || kind == rt::ENT_INNER)));   // boxes tested as written
-    if (special) done = walker_special<RELOAD, RELOAD && LDS>(sc, st, w, outer_a, outer_b, idx_slots ? idx_slots[lane_now()] : outer_idx);
+    if (special) done = walker_special<RELOAD, RELOAD && LDS, SAVE>(sc, st, w, outer_a, outer_b, idx_slots ? idx_slots[lane_now()] : outer_idx);
     RT_PROF(prof.special += __builtin_readcyclecounter() - t2;)
     return done;
 }

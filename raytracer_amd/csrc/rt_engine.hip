@@ -119,7 +119,7 @@ __device__ __forceinline__ bool cancelled(const Batch& bt) {
     return __hip_atomic_load(bt.cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == bt.serial;
 }
 struct Queues {
-    float4* a[2]; float4* b[2];      // ray records: a = (o.xyz, d.x), b = (d.y, d.z, slot, ctr | depth << 24)
+    float4* a[2]; float4* b[2];      // ray records: a = (o.xyz, d.x), b = (d.y, d.z, slot, ctr | depth << 24); b[k] = a[k] + capacity
     float4* hit;                     // hit records by queue position: (distance, best entry, u, v)
     uint32_t* hit_ctr;               // scenes with fog: the path's random-number counter after the traversal
     uint32_t* counts;                // counts[k] = rays entering pass k
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, C
     const uint32_t n_stripes = (n_in + STRIPE - 1) / STRIPE;
     uint32_t range = blockIdx.x % NCUR;
     // RELOAD, LEAN: see walker_special.  The lean variant also keeps the queue position of the lane's ray in LDS.
-    constexpr bool RELOAD = !FIRST && (!STAGED || BLOCK != IBLOCK), LEAN = RELOAD && STAGED;
+    constexpr bool RELOAD = BLOCK != IBLOCK || (!FIRST && !STAGED), LEAN = RELOAD && STAGED;
     uint32_t* my_slot = nullptr;   // wave-uniform: slot [lane] is this lane's
     if constexpr (LEAN) my_slot = lane_slots<BLOCK>() + __builtin_amdgcn_readfirstlane(threadIdx.x & ~63u);
     Walker w;
@@ -312,9 +312,14 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, C
                         const uint32_t seen = __hip_atomic_load(q.cursors + lane * CUR_STRIDE + pass, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         left = seen < sz ? sz - seen : 0u;
                     }
-                    uint32_t best = left << 6 | lane;          // left < 2^26: a queue holds fewer than 2^31 positions, a range 1/32 of them
-                    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)best, d); best = o > best ? o : best; }
-                    best = __builtin_amdgcn_readfirstlane(best);          // the same in every lane by now
+                    // the range with the most left, found with scalar instructions (a butterfly of lane exchanges would
+                    // keep six lane numbers in vector registers through the whole kernel for this rare step)
+                    uint32_t best = 0;                                    // left < 2^26: a queue holds fewer than 2^31 positions, a range 1/32 of them
+#pragma unroll
+                    for (int r = 0; r < NCUR; r++) {
+                        const uint32_t c = __builtin_amdgcn_readlane(left, r) << 6 | (uint32_t)r;
+                        best = c > best ? c : best;
+                    }
                     if ((best >> 6) == 0u) break;                         // nothing left anywhere
                     range = best & 63u;
                     chunk = (uint32_t)tune.min_chunk;
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, C
                     if (walker_is_idle(w) && o < mine_end && idx < n_in) {
                         Ray ray; Rng rng; uint32_t slot, depth;
                         if (fetch_ray<true>(cam_now, g_now, bt_now, q, qin, dbg, idx, ray, rng, slot, depth, FOG)) {
-                            my_idx = idx;
+                            if constexpr (LEAN) my_slot[lane_now()] = idx; else my_idx = idx;
                             walker_start<CULL>(sc, st, w, ray, rng);
                         }
                     }
@@ -343,6 +348,9 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, C
                         walker_start<CULL>(sc, st, w, ray, rng);
                     }
                 }
+                // the lean variant reads the entry every lane stands on again (it is what the lane holds already: every
+                // change of position ends in a load), so the entry's seven registers are free while rays are fetched
+                if constexpr (LEAN) walker_load(st, w);
                 const uint32_t took = (uint32_t)__popcll(idle);
                 mine = mine + took < mine_end ? mine + took : mine_end;
                 RT_PROF(n_refills++;)
@@ -360,7 +368,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, C
         // registers allow, was measured on both kinds of scene and gained nothing: 256-thread blocks on the
         // 100 000-primitive scene 92.9 against 92.3 ms; 640-thread blocks with the scene in LDS lose a fifth,
         // their ten waves do not spread evenly over four SIMDs.)
-        if (walk_round<STAGED, FOG, RELOAD>(sc, st, w, tune.quorum, tune.prim_quorum, tune.finish_quorum, prof, n_box, q.a[qin], q.b[qin], my_idx, q.hit, my_slot)) {
+        if (walk_round<STAGED, FOG, RELOAD, FIRST>(sc, st, w, tune.quorum, tune.prim_quorum, tune.finish_quorum, prof, n_box, q.a[qin], q.b[qin], my_idx, q.hit, my_slot)) {
             // (the lean walker has written the barycentrics of its winning triangle already)
             if constexpr (LEAN) *reinterpret_cast<float2*>(q.hit + my_slot[lane_now()]) = make_float2(w.c.dist, __int_as_float(w.c.best));
             else q.hit[my_idx] = make_float4(w.c.dist, __int_as_float(w.c.best), w.c.u, w.c.v);
@@ -693,6 +701,7 @@ struct rt_engine {
     Tune tune{32, 16, 8, 256, 16, 64, 16, 1};
     int quorum_mem = 24;                // Tune::quorum for scenes read from memory (RT_QUORUM sets both)
     int wide_blocks = -1;               // 768-thread bounce passes: -1 by batch size, 0 never, 1 always (RT_WIDE_BLOCKS)
+    int wide_first = 1;                 // ... and the camera rays' pass too (RT_WIDE_FIRST)
     int wide_max_pass = 3;              // ... up to this bounce (later passes hold a few per cent of the paths: 17.45 -> 17.35 ms)
     int win[4] = {0, 0, 0, 0};          // x0, y0, width, height of the render window
     // statistics of the last render
@@ -777,8 +786,8 @@ void launch_intersect(rt_engine* e, hipStream_t st, const Cfg& g, const Batch& b
     // an eighth of that frame 4.94 -> 5.1 ms), so the shape follows the size of the batch and the depth of the pass.
     // The variant keeps one dword per thread in LDS beside the scene (it has no register left for it).
     const bool wide = e->wide_blocks < 0 ? (long long)bt.n_pixels * (g.S * g.S) >= WIDE_MIN_PATHS : e->wide_blocks != 0;
-    if (e->staged_bytes && e->staged_bytes + 768 * sizeof(uint32_t) <= (size_t)MAX_STAGED_BYTES && !fog && !FIRST && wide && pass <= e->wide_max_pass) {
-        hipLaunchKernelGGL((intersect_kernel<false, true, false, 768, 6>), dim3(blocks), dim3(768), e->staged_bytes, st, e->sc, e->cam, g, bt, q, pass, e->dbg, tune);
+    if (e->staged_bytes && e->staged_bytes + 768 * sizeof(uint32_t) <= (size_t)MAX_STAGED_BYTES && !fog && wide && pass <= e->wide_max_pass && (!FIRST || e->wide_first)) {
+        hipLaunchKernelGGL((intersect_kernel<FIRST, true, false, 768, 6>), dim3(blocks), dim3(768), e->staged_bytes, st, e->sc, e->cam, g, bt, q, pass, e->dbg, tune);
         return;
     }
     if (e->staged_bytes) { if (fog) RT_LAUNCH_INTERSECT(true, true, e->staged_bytes); else RT_LAUNCH_INTERSECT(true, false, e->staged_bytes); }
@@ -880,8 +889,10 @@ int init_engine(rt_engine* e, const rt_config* cfg) {
     HIP_TRY(hipGetSymbolAddress((void**)&e->d_scratch, HIP_SYMBOL(scratch)));
     const size_t cap = (size_t)e->q.capacity;
     for (int k = 0; k < 2; k++) {
-        HIP_TRY(hipMalloc((void**)&e->q.a[k], cap * sizeof(float4)));
-        HIP_TRY(hipMalloc((void**)&e->q.b[k], cap * sizeof(float4)));
+        // one allocation, b behind a: the camera rays' pass also uses the input queue of the pass after it, empty until
+        // then, as `cap` records of 32 bytes (walker_special, SAVE)
+        HIP_TRY(hipMalloc((void**)&e->q.a[k], 2 * cap * sizeof(float4)));
+        e->q.b[k] = e->q.a[k] + cap;
     }
     HIP_TRY(hipMalloc((void**)&e->q.hit, cap * sizeof(float4)));
     HIP_TRY(hipMalloc((void**)&e->q.hit_ctr, cap * sizeof(uint32_t)));
@@ -899,6 +910,7 @@ int init_engine(rt_engine* e, const rt_config* cfg) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<false, true, false, 768, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<true, true, false, 768, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
 #ifdef RT_PROFILE
@@ -914,6 +926,7 @@ int init_engine(rt_engine* e, const rt_config* cfg) {
     if (const char* v = getenv("RT_FINISH_QUORUM")) e->tune.finish_quorum = std::max(1, std::min(65, atoi(v)));
     if (const char* v = getenv("RT_WIDE_BLOCKS")) e->wide_blocks = atoi(v) ? 1 : 0;
     if (const char* v = getenv("RT_WIDE_MAX_PASS")) e->wide_max_pass = atoi(v);
+    if (const char* v = getenv("RT_WIDE_FIRST")) e->wide_first = atoi(v);
     if (const char* v = getenv("RT_PRIM_QUORUM")) e->tune.prim_quorum = std::max(1, std::min(65, atoi(v)));
     return RT_OK;
 }
@@ -926,7 +939,7 @@ void rt_engine_destroy(rt_engine* e) {
     (void)hipSetDevice(e->cfg.device);
     (void)wait_all(e);
     free_scene(e);
-    for (int k = 0; k < 2; k++) { (void)hipFree(e->q.a[k]); (void)hipFree(e->q.b[k]); }
+    for (int k = 0; k < 2; k++) (void)hipFree(e->q.a[k]);   // (b[k] is its second half)
     (void)hipFree(e->q.hit); (void)hipFree(e->q.hit_ctr);
     (void)hipFree(e->q.stack); (void)hipFree(e->q.radiance); (void)hipFree(e->d_frame); (void)hipFree(e->d_counts_all);
     (void)hipFree(e->dbg.primary_id); (void)hipFree(e->dbg.primary_t); (void)hipFree(e->dbg.rng_draws);
