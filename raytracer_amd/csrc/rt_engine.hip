@@ -44,7 +44,7 @@ static __device__ __align__(256) unsigned char scratch[(size_t)RT_TRACE_STATIC_M
 namespace {
 
 constexpr int IBLOCK = 512;         // intersect: 8 waves per block; two blocks per CU, each with its own copy of the scene in LDS
-constexpr long long WIDE_MIN_PATHS = 1ll << 26;   // batches of at least this many paths run their bounce passes with 768-thread blocks
+constexpr long long WIDE_MIN_PATHS = 1ll << 24;   // batches of at least this many paths run their large passes with 768-thread blocks
 constexpr int MAX_STAGED_BYTES = 80 * 1024;   // largest scene copy a block keeps in LDS (two blocks share a CU's 160 KiB)
 // Reservation counters of the intersect passes: the queue of a pass is cut into NCUR ranges with a counter each (a single
 // counter would take every reservation of the grid, and additions to one address are served one after another); the
@@ -337,15 +337,17 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, C
                     if (walker_is_idle(w) && o < mine_end && idx < n_in) {
                         Ray ray; Rng rng; uint32_t slot, depth;
                         if (fetch_ray<true>(cam_now, g_now, bt_now, q, qin, dbg, idx, ray, rng, slot, depth, FOG)) {
-                            if constexpr (LEAN) my_slot[lane_now()] = idx; else my_idx = idx;
                             walker_start<CULL>(sc, st, w, ray, rng);
+                            const uint32_t tagged = RELOAD && w.usable ? idx | IDX_USABLE : idx;
+                            if constexpr (LEAN) my_slot[lane_now()] = tagged; else my_idx = tagged;
                         }
                     }
                 } else if (walker_is_idle(w) && o < mine_end && idx < n_in) {
                     Ray ray; Rng rng; uint32_t slot, depth;
                     if (fetch_ray<false>(cam, g, bt, q, qin, dbg, idx, ray, rng, slot, depth, FOG)) {
-                        if constexpr (LEAN) my_slot[lane_now()] = idx; else my_idx = idx;
                         walker_start<CULL>(sc, st, w, ray, rng);
+                        const uint32_t tagged = RELOAD && w.usable ? idx | IDX_USABLE : idx;
+                        if constexpr (LEAN) my_slot[lane_now()] = tagged; else my_idx = tagged;
                     }
                 }
                 // the lean variant reads the entry every lane stands on again (it is what the lane holds already: every
@@ -361,18 +363,18 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, C
             if (drained) break;
             continue;
         }
-        // bounce passes of scenes read from memory: a lane inside an instance does not keep the ray as given, it reads it
-        // again from the queue on the way out (97 registers instead of 110).  Not with the scene in LDS: there the blocks
-        // are bounded by LDS, and reading the ray again cost 0.3 ms of a C2 frame — except in the 768-thread variant
-        // (launch_intersect), which needs the registers for its sixth wave per SIMD.  (A fifth wave per SIMD, which 96
-        // registers allow, was measured on both kinds of scene and gained nothing: 256-thread blocks on the
-        // 100 000-primitive scene 92.9 against 92.3 ms; 640-thread blocks with the scene in LDS lose a fifth,
-        // their ten waves do not spread evenly over four SIMDs.)
+        // RELOAD — bounce passes of scenes read from memory: a lane inside an instance does not keep the ray as given, it
+        // reads it again from the queue on the way out (ten registers).  With the scene in LDS only the 768-thread
+        // variants do so (launch_intersect): they need the registers for their sixth wave per SIMD, while the 512-thread
+        // blocks are bounded by LDS and reading the ray again cost them 0.3 ms of a 1080p, 64 spp frame.  (A fifth wave
+        // per SIMD was measured on both kinds of scene and gained nothing: 256-thread blocks on the 100 000-primitive
+        // scene 92.9 against 92.3 ms; 640-thread blocks with the scene in LDS lose a fifth, their ten waves do not spread
+        // evenly over four SIMDs.)
         if (walk_round<STAGED, FOG, RELOAD, FIRST>(sc, st, w, tune.quorum, tune.prim_quorum, tune.finish_quorum, prof, n_box, q.a[qin], q.b[qin], my_idx, q.hit, my_slot)) {
             // (the lean walker has written the barycentrics of its winning triangle already)
-            if constexpr (LEAN) *reinterpret_cast<float2*>(q.hit + my_slot[lane_now()]) = make_float2(w.c.dist, __int_as_float(w.c.best));
-            else q.hit[my_idx] = make_float4(w.c.dist, __int_as_float(w.c.best), w.c.u, w.c.v);
-            if (FOG) q.hit_ctr[my_idx] = w.rng.ctr;
+            if constexpr (LEAN) *reinterpret_cast<float2*>(q.hit + (my_slot[lane_now()] & IDX_MASK)) = make_float2(w.c.dist, __int_as_float(w.c.best));
+            else q.hit[my_idx & IDX_MASK] = make_float4(w.c.dist, __int_as_float(w.c.best), w.c.u, w.c.v);
+            if (FOG) q.hit_ctr[my_idx & IDX_MASK] = w.rng.ctr;
         }
     }
     if (lane_now() == 0 && n_box) atomicAdd(reinterpret_cast<unsigned long long*>(q.counts + BOX_COUNT_AT) + pass, (unsigned long long)n_box);
@@ -780,11 +782,12 @@ void launch_intersect(rt_engine* e, hipStream_t st, const Cfg& g, const Batch& b
     if (!e->staged_bytes) tune.quorum = e->quorum_mem;
 #define RT_LAUNCH_INTERSECT(STAGED, FOG, LDS_BYTES) \
     hipLaunchKernelGGL((intersect_kernel<FIRST, STAGED, FOG>), dim3(blocks), dim3(IBLOCK), LDS_BYTES, st, e->sc, e->cam, g, bt, q, pass, e->dbg, tune)
-    // Large bounce passes over a scene in LDS: 768-thread blocks, twelve waves that spread evenly over the four SIMDs, two
-    // blocks per CU as before: six waves per SIMD instead of four (80 registers).  Measured on the 1920 x 1080 x 64 spp
-    // frame: 18.0 -> 17.5 ms in the intersect kernels.  Small passes lose with larger blocks (more waves wait at the end:
-    // an eighth of that frame 4.94 -> 5.1 ms), so the shape follows the size of the batch and the depth of the pass.
-    // The variant keeps one dword per thread in LDS beside the scene (it has no register left for it).
+    // Large passes over a scene in LDS: 768-thread blocks, twelve waves that spread evenly over the four SIMDs, two blocks
+    // per CU as before: six waves per SIMD instead of four, for which the kernel stays within 80 registers (RELOAD, LEAN,
+    // SAVE in rt_device.h; the variant keeps one dword per thread in LDS beside the scene).  Measured on the 1920 x 1080
+    // x 64 spp frame: 18.0 -> 16.0 ms in the intersect kernels; on a half, a quarter and an eighth of it 14.4 -> 13.2,
+    // 7.96 -> 7.84 and 4.89 -> 4.84 ms per frame; on 1280 x 720 x 9 spp 2.37 -> 2.45 ms: small passes lose with larger
+    // blocks (more waves wait at the end), so the shape follows the size of the batch and the depth of the pass.
     const bool wide = e->wide_blocks < 0 ? (long long)bt.n_pixels * (g.S * g.S) >= WIDE_MIN_PATHS : e->wide_blocks != 0;
     if (e->staged_bytes && e->staged_bytes + 768 * sizeof(uint32_t) <= (size_t)MAX_STAGED_BYTES && !fog && wide && pass <= e->wide_max_pass && (!FIRST || e->wide_first)) {
         hipLaunchKernelGGL((intersect_kernel<FIRST, true, false, 768, 6>), dim3(blocks), dim3(768), e->staged_bytes, st, e->sc, e->cam, g, bt, q, pass, e->dbg, tune);
