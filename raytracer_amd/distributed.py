@@ -36,8 +36,8 @@ class TileRenderer:
     sequence taking the engines in turn, each on its own stream.  A rank's share of a frame runs passes that are too
     small to fill its GPU (the deep bounces of an eighth of a frame are a few thousand rays each); with two or three
     frames in flight those passes run beside the large passes of the next frame.  Measured on one MI355X with rank 0's
-    share of the 1920 x 1080 x 64 spp frame: 8 ranks 4.96 ms per frame with one frame in flight, 4.11 with three; 4 ranks
-    8.03 and 7.55; 2 ranks and the whole frame gain nothing (two full-size persistent grids only take turns).
+    share of the 1920 x 1080 x 64 spp frame: 8 ranks 4.80 ms per frame with one frame in flight, 3.86 with three; 4 ranks
+    7.72 and 6.99; 2 ranks and the whole frame gain nothing (two full-size persistent grids only take turns).
     group: a torch.distributed process group or None for the default; world size 1 needs no process group at all."""
 
     def __init__(self, engine, device, rank=0, world_size=1, group=None, display_rank=0):
