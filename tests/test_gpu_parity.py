@@ -342,6 +342,10 @@ def test_c2_full_frame_properties(rt, gpu_default, monkeypatch):
     e3 = make_engine(rt, gpu_default, W, H, S, B)
     monkeypatch.delenv("RT_WIDE_BLOCKS")
     assert_bits(e3.render_frame(7), a, "512-thread against 768-thread bounce passes")
+    # the frame in four batches, each still large enough for the 768-thread variants (whose camera-ray pass parks rays in
+    # the queue of the pass after it): batches follow one another through the same queues
+    e4 = make_engine(rt, gpu_default, W, H, S, B, max_batch_paths=1 << 25)
+    assert_bits(e4.render_frame(7), a, "four batches against one")
 
 
 def test_error_behaviour(rt, gpu_default):
