@@ -312,6 +312,12 @@ def run_workload(job, rt, workload, steps, warmup, batch_paths=0, in_flight=1):
     from raytracer_amd.distributed import TileRenderer
     desc, W, H, S, B = WORKLOADS[workload]
     scene, cam, build_s = build_scene(rt, workload)
+    if job.world > 1 and not batch_paths:
+        # the queues of an engine are sized for one batch: a rank only ever renders its share of the tiles, so a batch of
+        # that size (not of the whole frame) keeps its passes in one piece and the allocation at 1/world
+        c0 = rt.default_config(width=W, height=H, samples_per_axis=S, bounces=B)
+        tiles = -(-W // c0.tile_w) * -(-H // c0.tile_h)
+        batch_paths = min(-(-tiles // job.world) * c0.tile_w * c0.tile_h * S * S, 1 << 27)
     engs = []
     for _ in range(max(1, in_flight)):
         eng = rt.Engine(rt.default_config(width=W, height=H, samples_per_axis=S, bounces=B, device=job.local_rank,
