@@ -546,9 +546,11 @@ __device__ __forceinline__ void walker_start(const Scene& sc, const Store& st, W
 //     pairs);
 //   * the lanes that act are enabled through exec inside the block (restored before every test and at the end), so the
 //     surrounding control flow is wave-uniform.
-// v2..v15 are used as scratch registers by name because the halves of a register pair cannot be named through operands;
-// the exact quotients' residuals go into the registers of the entry itself, which the box step has consumed by then and
-// the fetch at the end of the iteration overwrites for every lane that stepped.
+// Scratch registers are used by name because the halves of a register pair cannot be named through operands: v2..v15
+// with the scene in memory, v8..v15 with the scene in LDS (there products and selects are formed in place, and the exact
+// quotients are computed one axis after the other, so that the kernel variants that run six waves per SIMD stay within
+// their 80 registers).  The exact quotients' residuals go into the registers of the entry itself, which the box step has
+// consumed by then and the fetch at the end of the iteration overwrites for every lane that stepped.
 // Every lane of the wave must be enabled at the call.
 // RT_PROFILE builds (make PROF=1) time the phases of every round with the shader clock; see intersect_kernel
 struct Prof { unsigned long long box = 0, prim = 0, special = 0, refill = 0; unsigned rounds = 0, prims = 0, prim_lanes = 0, specials = 0, box_iters = 0, box_lanes = 0, finishes = 0, finish_lanes = 0; };
