@@ -458,7 +458,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--batch-paths", type=int, default=0)
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="engines per rank taking the frames in turn; 0 = 3 from four GPUs on, else 1 (what a rank's share of "
+                    help="engines per rank taking the frames in turn; 0 = 3 from two GPUs on, else 1 (what a rank's share of "
                          "the frame measured best with on one GPU: tools/frames_in_flight.py)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks all on GPU 0 with a gloo group (staged through the host): checks the multi-process "
@@ -471,7 +471,7 @@ def main():
     threads = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))
     with_cpu = (not args.no_cpu_baseline) and world == 1
 
-    in_flight = args.frames_in_flight or (3 if world >= 4 and args.workload == "c2" else 1)
+    in_flight = args.frames_in_flight or (3 if world >= 2 and args.workload == "c2" else 1)
     r = run_workload(job, rt, args.workload, args.steps, args.warmup, args.batch_paths, in_flight)
     desc, W, H, S, B = r["desc"], r["W"], r["H"], r["S"], r["B"]
     out = None
