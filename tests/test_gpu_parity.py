@@ -7,6 +7,8 @@ with the oracle (portable math) — integer, index and float work alike.  Agains
 distances are bit-exact; 8-bit colour may differ where libm's sinf/atan2f and the portable versions round differently
 (a skybox texel or a checker cell flips): tolerance stated in assert_frame_close.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -584,7 +586,16 @@ def test_degenerate_scenes_and_sizes(rt, orc, assets, case):
     assert_bits(frame, ref["rgba"], case + ": frame")
 
 
-@pytest.mark.parametrize("seed", [101, 202, 303, 404, 505, 606, 707, 808])
+# RT_EXTRA_SEEDS="a-b" adds the seeds a..b-1 for a wider sweep than the suite's eight scenes
+def _extra_seeds():
+    spec = os.environ.get("RT_EXTRA_SEEDS", "")
+    if "-" not in spec:
+        return []
+    lo, hi = spec.split("-", 1)
+    return list(range(int(lo), int(hi)))
+
+
+@pytest.mark.parametrize("seed", [101, 202, 303, 404, 505, 606, 707, 808] + _extra_seeds())
 def test_random_scenes_bit_exact(rt, orc, assets, seed, monkeypatch):
     """scenes nobody arranged: ids, distances, draw counts, radiance and frame bytes against the oracle, bit for bit"""
     tex, mat, obj, plane, (pos, look) = random_tables(seed)
