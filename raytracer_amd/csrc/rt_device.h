@@ -247,9 +247,13 @@ __device__ __forceinline__ uint32_t f2u_x86(float f) {
     if (!(f > -9.2233720368547758e18f && f < 9.2233720368547758e18f)) return 0u;
     return (uint32_t)(unsigned long long)(long long)f;
 }
+// Texture coordinates the reference can produce lie in [0, 1] and index at most one row past the image (the tables are
+// padded by that row); the index is held there so that coordinates no scene produces (a caller's ray with components
+// that overflow, say) read the padding instead of memory outside the table.  Nothing changes for indices in range.
+__device__ __forceinline__ uint32_t texel_in_table(uint32_t texel, uint32_t w, uint32_t h) { return min(texel, w * h + w); }
 __device__ __forceinline__ int image_index(const rt::ImageRec im, float u, float v) {   // DataUtility.h:82 (uvec2 size: unsigned arithmetic)
     const uint32_t row = (uint32_t)(int)(v * (float)im.h), col = (uint32_t)(int)(u * (float)im.w);
-    return 4 * (int)(row * im.w + col);
+    return 4 * (int)texel_in_table(row * im.w + col, im.w, im.h);
 }
 // Triangle::Intersect (Object.cpp:498-550).  alpha_off >= 0: the material's image texture decides solidity
 // (DataUtility.cpp:123-127: alpha byte > 0.01f, i.e. alpha >= 1) — looked up in a one-bit-per-texel copy of the alpha
@@ -302,7 +306,7 @@ __device__ __forceinline__ bool tri_surface(const Scene& sc, const float4* tris,
     uo = uu; vo = vv;
     if (alpha_off >= 0) {
         const uint32_t w = alpha_wh & 0xFFFFu, h = alpha_wh >> 16;
-        const uint32_t texel = (uint32_t)(int)(vv * (float)h) * w + (uint32_t)(int)(uu * (float)w);   // DataUtility.h:82
+        const uint32_t texel = texel_in_table((uint32_t)(int)(vv * (float)h) * w + (uint32_t)(int)(uu * (float)w), w, h);   // DataUtility.h:82
         if (!((sc.alpha_bits[(uint32_t)alpha_off + (texel >> 5)] >> (texel & 31u)) & 1u)) return false;
     }
     return true;
@@ -1043,7 +1047,7 @@ __device__ inline V3 skybox_pixel(const Scene& sc, V3 d) {
     const float u = pm_atan2f(d.x, d.z) / (2 * 3.14159265358979323846264338327950288f) + 0.5f;
     const float v = d.y * 0.5f + 0.5f;
     const int ix = (int)(u * (float)sc.sky_w), iy = (int)(v * (float)sc.sky_h);
-    const int index = 3 * (int)((uint32_t)iy * sc.sky_w + (uint32_t)ix);
+    const int index = 3 * (int)texel_in_table((uint32_t)iy * sc.sky_w + (uint32_t)ix, sc.sky_w, sc.sky_h);
     return texel_color(sc.texels + sc.sky_off + (uint32_t)index);
 }
 // The sign of pm_sinf(x) without its polynomial: 1 negative, 0 positive, -1 when this shortcut cannot tell (the value is

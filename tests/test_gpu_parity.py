@@ -141,6 +141,19 @@ def test_ray_color_default_scene(rt, golden, oracle_default, gpu_default):
     assert same > 0.995, same
 
 
+def test_ray_queries_off_the_unit_sphere_stay_inside_the_tables(rt, oracle_default, gpu_default):
+    """The skybox and texture lookups are not clamped in the reference (World.cpp:173-193, DataUtility.h:82): a direction
+    that is not of unit length indexes rows past the image there.  The engine holds such an index in the table's padding
+    row; rays with unit directions in the same call are untouched."""
+    o = np.array([[0, 3, -10]] * 5, dtype=np.float32)
+    d = np.array([[0, 5, 0], [0, -7, 0.1], [3, 4, 12], [-2, 9, 1], [0, 0, 1]], dtype=np.float32)
+    keys = np.arange(5, dtype=np.uint32) * 2654435761 + 5
+    e = make_engine(rt, gpu_default, 64, 64, 1, 3)
+    col = e.ray_color(o, d, 3, keys)
+    assert col.shape == (5, 3) and np.isfinite(col).all()
+    assert_bits(col[4:], oracle_default.ray_color(o[4:], d[4:], 3, keys[4:]), "the unit-length ray of the call")
+
+
 @pytest.mark.parametrize("W,H,S,B", [(256, 144, 3, 3), (160, 90, 2, 8), (67, 45, 4, 0)])
 def test_render_small_frames_bit_exact(rt, oracle_default, gpu_default, W, H, S, B):
     cam = rt.camera_look(CAM_POS, CAM_LOOK)
