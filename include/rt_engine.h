@@ -159,13 +159,19 @@ int rt_engine_assemble(rt_engine* e, const uint8_t* d_gathered, int n_ranks, uin
 /* Waits for everything the engine has queued: its own stream and, when the latest rt_engine_render / rt_engine_assemble
  * was given a stream of the caller's, that stream as well.  rt_engine_poll, rt_engine_read_frame, rt_engine_get_stats
  * and rt_engine_set_scene follow the same rule.  A caller that spreads work over several streams of its own orders
- * them itself. */
+ * them itself.  The engine keeps the handle of a caller's stream from the render / assemble / clear_frame that named it
+ * until the first of these waits has returned, and not beyond: the stream must stay valid until then (or until
+ * rt_engine_destroy, which waits too), and may be destroyed afterwards. */
 int rt_engine_sync(rt_engine* e);
 /* 1 when everything queued on the engine's stream has finished, 0 while work is still running — what the front end's
  * FrameManager::NeedUpdatingTexture (FrameManager.cpp:40-48) learns from its per-thread flags.  Never blocks. */
 int rt_engine_poll(rt_engine* e);
 /* FrameManager::GetTexturePixelsToPresent (FrameManager.cpp:60-71): waits, then copies the engine's own frame buffer. */
 int rt_engine_read_frame(rt_engine* e, uint8_t* rgba_out);
+/* The pixels [x0,x1) x [y0,y1) of the engine's own frame buffer, rows of (x1 - x0) * 4 bytes one after another: what
+ * World::CalculateColorForScreenPosition (World.cpp:68-102, FrameManager.cpp:89-94) yields for those pixels.  Waits like
+ * rt_engine_read_frame. */
+int rt_engine_read_rect(rt_engine* e, int x0, int y0, int x1, int y1, uint8_t* rgba_out);
 /* The same frame without a second copy: a pointer to the engine's own page-locked host buffer (width*height*4 bytes, same
  * layout), valid until the next rt_engine_map_frame or rt_engine_destroy.  wait != 0: the complete frame, after everything
  * queued has finished; the device-to-host copy runs on the render's stream right behind it.  wait == 0: the frame buffer
@@ -197,7 +203,9 @@ int rt_engine_trace(rt_engine* e, int n, const float* origins3, const float* dir
  * results as rt_engine_trace, at most RT_TRACE_STATIC_MAX_RAYS rays per call (more: RT_E_INVALID).  The rays and results
  * are staged in a static 2 MiB device array that every GPU the library runs on holds until the process ends; calls on
  * the same GPU share it, so calls that overlap on one GPU (from several engines or threads) race and must be serialised
- * by the caller.  Calls no hipMalloc / hipFree and no allocating library routine. */
+ * by the caller.  Like rt_engine_trace it first waits for what the engine has queued.  Calls no hipMalloc / hipFree and no
+ * allocating library routine: the caller's arrays are copied through a page-locked mirror of the staging array that the
+ * engine allocated when it was created, so every transfer is between page-locked and device memory. */
 #define RT_TRACE_STATIC_MAX_RAYS 32768
 int rt_engine_trace_static(rt_engine* e, int n, const float* origins3, const float* dirs3, int32_t* hit_id, float* rec9);
 /* World::GetRayColor (World.cpp:104-171) for arbitrary rays, one RNG key per ray. */
@@ -226,7 +234,9 @@ int rt_engine_check_division(rt_engine* e, int n, const float* a, const float* b
  * Several GPUs behind one handle, in one process — for a front end that owns one FrameManager (App.h:27) and should use
  * a whole node: FrameManager.cpp:17-21 splits the frame over THREAD_COUNT threads, this splits it over n_dev devices.
  * The scene is replicated; device k renders tiles k, k+n, ...; the first device of the list gathers the others' tiles
- * with peer-to-peer copies and holds the frame.  All calls queue work and return, except sync and map_frame(wait).
+ * with peer-to-peer copies and holds the frame.  All calls queue work and return, except sync and map_frame(wait);
+ * frames may be queued one behind the other without waiting in between (a device's next render waits on the GPU until
+ * the display device has taken its tiles of the frame before).
  * A device may be listed more than once.  rt_multi_engine(m, k) gives engine k (statistics, queries); engine 0 is the
  * display engine, whose own frame buffer receives the frame.
  * ------------------------------------------------------------------------------------------------------- */

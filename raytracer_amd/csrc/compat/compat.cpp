@@ -70,12 +70,10 @@ glm::u8vec3 World::CalculateColorForScreenPosition(int x, int y) {
     rt_engine* engine = Engine();
     check(rt_engine_set_window(engine, x, y, x + 1, y + 1), "rt_engine_set_window");
     check(rt_engine_render(engine, frameSeed, 0, 1, nullptr, nullptr), "rt_engine_render");
-    static thread_local std::vector<uint8_t> frame;
-    frame.resize((size_t)WINDOW_WIDTH * WINDOW_HEIGHT * 4);
-    check(rt_engine_read_frame(engine, frame.data()), "rt_engine_read_frame");
+    uint8_t p[4];                        // stored [A,B,G,R] (FrameManager.cpp:91-94)
+    check(rt_engine_read_rect(engine, x, y, x + 1, y + 1, p), "rt_engine_read_rect");
     check(rt_engine_set_window(engine, 0, 0, WINDOW_WIDTH, WINDOW_HEIGHT), "rt_engine_set_window");
-    const uint8_t* p = &frame[((size_t)y * WINDOW_WIDTH + x) * 4];
-    return glm::u8vec3(p[3], p[2], p[1]);   // stored [A,B,G,R] (FrameManager.cpp:91-94)
+    return glm::u8vec3(p[3], p[2], p[1]);
 }
 glm::vec3 World::GetRayColor(const Ray& ray, int bounceAmount) {
     const float o[3] = {ray.pos.x, ray.pos.y, ray.pos.z}, d[3] = {ray.direction.x, ray.direction.y, ray.direction.z};

@@ -2,8 +2,8 @@
 //
 // They produce what the reference's loaders produce for the same files:
 //   * OBJ: LoadOBJ (Object.cpp:349-435): v / vt / vn / f records, 1-based and negative (relative) indices, fan
-//     triangulation, face normal when a corner names no normal.  Numbers are parsed with the same iostream
-//     extraction the reference uses, so every float has the same bits.
+//     triangulation, face normal when a corner names no normal.  Every field yields the value the reference's parser
+//     gives it (strtof on the same characters), so every float has the same bits.
 //   * PNG: the stb_image calls of DataUtility.cpp:17-28,98-109 — rows flipped vertically, a requested channel count.
 //     Decoding is done here with zlib's inflate and the PNG filters (PNG spec, sections 9 and 8.2 Adam7).
 #include "rt_host.h"
@@ -12,72 +12,158 @@
 
 #include <algorithm>
 
+#include <cfloat>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <fstream>
-#include <sstream>
 #include <string>
 #include <vector>
 
 namespace rt {
 
 // ------------------------------------------------------------------------------------------------- OBJ
+// The file is read whole and scanned in place: lines, blank-separated words, and inside a face word the '/'-separated
+// index fields.  What has to agree with the reference's parser (formatted stream extraction into floats, atoi on index
+// fields) is the VALUE every field yields, including the odd cases:
+//   * a number is [sign] digits [. digits] [e|E [sign] digits] as far as it goes; the text is converted by strtof, and
+//     a field that is not a number as a whole ("1e", "-", "abc") yields 0 and ends the record: the fields after it
+//     keep their defaults (x y z u v i j k = 0, w = 1), as do fields the line does not have;
+//   * an index field is an optional sign and digits; anything else (or nothing) counts as 0 = "not given";
+//   * negative indices count back from the end of what has been read so far; a face with more than three corners is a
+//     fan about its first corner; a corner without a normal gets the face's own (Object.cpp:349-435).
+namespace {
+struct Text {
+    const char* at;
+    const char* end;
+    bool done() const { return at >= end; }
+};
+inline bool blank(char c) { return c == ' ' || (c >= '\t' && c <= '\r'); }
+// the next line of `file` (without its '\n'); false at the end of the file
+bool next_line(Text& file, Text& line) {
+    if (file.done()) return false;
+    const char* nl = static_cast<const char*>(memchr(file.at, '\n', (size_t)(file.end - file.at)));
+    line.at = file.at;
+    line.end = nl ? nl : file.end;
+    file.at = nl ? nl + 1 : file.end;
+    return true;
+}
+// the next blank-separated word of `line`; false when only blanks are left
+bool next_word(Text& line, Text& word) {
+    while (!line.done() && blank(*line.at)) line.at++;
+    if (line.done()) return false;
+    word.at = line.at;
+    while (!line.done() && !blank(*line.at)) line.at++;
+    word.end = line.at;
+    return true;
+}
+bool word_is(const Text& w, const char* name) {
+    const size_t n = strlen(name);
+    return (size_t)(w.end - w.at) == n && memcmp(w.at, name, n) == 0;
+}
+// Up to `n` numbers from the rest of `line` into out[0..n), stopping at the first field that is missing or malformed.
+void take_numbers(Text line, float* out, int n) {
+    for (int k = 0; k < n; k++) {
+        while (!line.done() && blank(*line.at)) line.at++;
+        if (line.done()) return;                       // nothing left: this field and the rest keep their defaults
+        char text[64];
+        size_t len = 0;
+        bool digits = false, point = false, expo = false;
+        const char* p = line.at;
+        if (p < line.end && (*p == '+' || *p == '-')) text[len++] = *p++;
+        while (p < line.end && len + 1 < sizeof text) {
+            const char c = *p;
+            if (c >= '0' && c <= '9') digits = true;
+            else if (c == '.' && !point && !expo) point = true;
+            else if ((c == 'e' || c == 'E') && !expo && digits) {
+                expo = true;
+                text[len++] = c; p++;
+                if (p < line.end && (*p == '+' || *p == '-') && len + 1 < sizeof text) { text[len++] = *p++; }
+                continue;
+            } else break;
+            text[len++] = c; p++;
+        }
+        text[len] = 0;
+        line.at = p;
+        char* stop = text;
+        float v = len ? strtof(text, &stop) : 0.0f;
+        const bool whole = len && stop == text + len;
+        if (!whole) { out[k] = 0.0f; return; }         // not a number: zero, and the record ends here
+        if (std::isinf(v)) { out[k] = v > 0 ? FLT_MAX : -FLT_MAX; return; }   // out of range: clamped, and the record ends
+        out[k] = v;
+    }
+}
+// an index field [at, end): optional sign and digits, 0 for anything else
+int index_field(const char* at, const char* end) {
+    while (at < end && blank(*at)) at++;
+    bool neg = false;
+    if (at < end && (*at == '+' || *at == '-')) neg = *at++ == '-';
+    long long v = 0;
+    while (at < end && *at >= '0' && *at <= '9') { v = v * 10 + (*at++ - '0'); if (v > 0x7FFFFFFFll) v = 0x7FFFFFFFll; }
+    return (int)(neg ? -v : v);
+}
+}  // namespace
+
 bool load_obj(const std::string& path, std::vector<float>& verts8, std::string& err) {
-    std::ifstream in(path);
-    if (!in) { err = "cannot open OBJ file " + path; return false; }
-    struct Ref { int v, vt, vn; };
-    struct P4 { float x, y, z, w; };
-    std::vector<P4> positions(1, P4{0, 0, 0, 0});
-    std::vector<Vec3> texcoords(1, Vec3{0, 0, 0});
-    std::vector<Vec3> normals(1, Vec3{0, 0, 0});
-    std::string line;
+    std::vector<char> bytes;
+    {
+        FILE* fp = fopen(path.c_str(), "rb");
+        if (!fp) { err = "cannot open OBJ file " + path; return false; }
+        char chunk[1 << 16];
+        size_t got;
+        while ((got = fread(chunk, 1, sizeof chunk, fp)) > 0) bytes.insert(bytes.end(), chunk, chunk + got);
+        fclose(fp);
+    }
+    // tables are 1-based: slot 0 is the "not given" entry a zero index names
+    std::vector<float> pos(3, 0.0f), tex(2, 0.0f), nrm(3, 0.0f);
+    struct Corner { int p, t, n; };
+    std::vector<Corner> corners;
     verts8.clear();
-    while (std::getline(in, line)) {
-        std::istringstream ls(line);
-        std::string type;
-        ls >> type;
-        if (type == "v") {
-            float x = 0, y = 0, z = 0, w = 1;
-            ls >> x >> y >> z >> w;
-            positions.push_back(P4{x, y, z, w});
-        } else if (type == "vt") {
-            float u = 0, v = 0, w = 0;
-            ls >> u >> v >> w;
-            texcoords.push_back(Vec3{u, v, w});
-        } else if (type == "vn") {
-            float i = 0, j = 0, k = 0;
-            ls >> i >> j >> k;
-            normals.push_back(normalize(Vec3{i, j, k}));
-        } else if (type == "f") {
-            std::vector<Ref> refs;
-            std::string tok;
-            while (ls >> tok) {
-                std::istringstream rs(tok);
-                std::string a, b, c;
-                std::getline(rs, a, '/');
-                std::getline(rs, b, '/');
-                std::getline(rs, c, '/');
-                int v = atoi(a.c_str()), vt = atoi(b.c_str()), vn = atoi(c.c_str());
-                v = v >= 0 ? v : (int)positions.size() + v;
-                vt = vt >= 0 ? vt : (int)texcoords.size() + vt;
-                vn = vn >= 0 ? vn : (int)normals.size() + vn;
-                refs.push_back(Ref{v, vt, vn});
+    Text file{bytes.data(), bytes.data() + bytes.size()}, line, word;
+    while (next_line(file, line)) {
+        if (!next_word(line, word)) continue;
+        if (word_is(word, "v")) {
+            float f[4] = {0, 0, 0, 1};
+            take_numbers(line, f, 4);
+            pos.insert(pos.end(), f, f + 3);
+        } else if (word_is(word, "vt")) {
+            float f[3] = {0, 0, 0};
+            take_numbers(line, f, 3);
+            tex.insert(tex.end(), f, f + 2);
+        } else if (word_is(word, "vn")) {
+            float f[3] = {0, 0, 0};
+            take_numbers(line, f, 3);
+            const Vec3 n = normalize(Vec3{f[0], f[1], f[2]});
+            nrm.push_back(n.x); nrm.push_back(n.y); nrm.push_back(n.z);
+        } else if (word_is(word, "f")) {
+            const int n_pos = (int)pos.size() / 3, n_tex = (int)tex.size() / 2, n_nrm = (int)nrm.size() / 3;
+            corners.clear();
+            while (next_word(line, word)) {
+                int idx[3] = {0, 0, 0};
+                const char* at = word.at;
+                for (int k = 0; k < 3 && at <= word.end; k++) {
+                    const char* slash = static_cast<const char*>(memchr(at, '/', (size_t)(word.end - at)));
+                    const char* stop = slash ? slash : word.end;
+                    idx[k] = index_field(at, stop);
+                    at = stop + 1;
+                    if (!slash) break;
+                }
+                Corner c{idx[0], idx[1], idx[2]};
+                if (c.p < 0) c.p += n_pos;
+                if (c.t < 0) c.t += n_tex;
+                if (c.n < 0) c.n += n_nrm;
+                if (c.p < 0 || c.p >= n_pos || c.t < 0 || c.t >= n_tex || c.n < 0 || c.n >= n_nrm) { err = "OBJ index out of range in " + path; return false; }
+                corners.push_back(c);
             }
-            for (size_t i = 1; i + 1 < refs.size(); ++i) {
-                const Ref* p[3] = {&refs[0], &refs[i], &refs[i + 1]};
-                for (int j = 0; j < 3; j++)
-                    if (p[j]->v < 0 || p[j]->v >= (int)positions.size() || p[j]->vt < 0 || p[j]->vt >= (int)texcoords.size() ||
-                        p[j]->vn < 0 || p[j]->vn >= (int)normals.size()) { err = "OBJ index out of range in " + path; return false; }
-                const P4 &a = positions[p[0]->v], &b = positions[p[1]->v], &c = positions[p[2]->v];
-                Vec3 U{b.x - a.x, b.y - a.y, b.z - a.z}, V{c.x - a.x, c.y - a.y, c.z - a.z};
-                Vec3 face = normalize(cross(U, V));
-                for (int j = 0; j < 3; j++) {
-                    const P4& q = positions[p[j]->v];
-                    const Vec3& t = texcoords[p[j]->vt];
-                    Vec3 n = p[j]->vn != 0 ? normals[p[j]->vn] : face;
-                    const float row[8] = {q.x, q.y, q.z, t.x, t.y, n.x, n.y, n.z};
+            for (size_t k = 1; k + 1 < corners.size(); k++) {
+                const Corner tri[3] = {corners[0], corners[k], corners[k + 1]};
+                const float *a = &pos[3 * (size_t)tri[0].p], *b = &pos[3 * (size_t)tri[1].p], *c = &pos[3 * (size_t)tri[2].p];
+                const Vec3 face = normalize(cross(Vec3{b[0] - a[0], b[1] - a[1], b[2] - a[2]}, Vec3{c[0] - a[0], c[1] - a[1], c[2] - a[2]}));
+                for (const Corner& q : tri) {
+                    const float* pp = &pos[3 * (size_t)q.p];
+                    const float* tt = &tex[2 * (size_t)q.t];
+                    const Vec3 n = q.n ? Vec3{nrm[3 * (size_t)q.n], nrm[3 * (size_t)q.n + 1], nrm[3 * (size_t)q.n + 2]} : face;
+                    const float row[8] = {pp[0], pp[1], pp[2], tt[0], tt[1], n.x, n.y, n.z};
                     verts8.insert(verts8.end(), row, row + 8);
                 }
             }

@@ -53,6 +53,7 @@ constexpr int NCUR = 32, CUR_STRIDE = 1024;
 constexpr int STRIPE = 512;          // positions per stripe; range r of a queue is every NCUR-th stripe, starting with stripe r
 constexpr int COUNT_WORDS = CUR_STRIDE * (1 + NCUR);   // per batch: ray counts per pass, then NCUR rows of counters
 constexpr int BOX_COUNT_AT = 512;   // words BOX_COUNT_AT + 2k, + 2k + 1 of a batch's first row: box tests executed by pass k (64 bits)
+constexpr long long MAX_BATCHES = 4096;   // batches per frame an engine reserves pass counters for (0.5 GiB of counters at most)
 constexpr int STILE = 1024;         // shade: queue positions a block handles per round (survivors staged in 32 KiB of LDS)
 // intersect scheduling knobs (defaults in rt_engine_create; RT_REFILL_AT / RT_QUORUM / RT_CHUNK override them for tuning)
 struct Tune {
@@ -682,13 +683,16 @@ struct rt_engine {
     hipStream_t stream = nullptr;
     hipStream_t last_stream = nullptr;  // the stream of the latest render / assemble when the caller brought its own
     unsigned char* d_scratch = nullptr; // this device's copy of the static staging array (rt_engine_trace_static)
+    unsigned char* h_stage = nullptr;   // page-locked host mirror of it, allocated with the engine: the copies of rt_engine_trace_static
+                                        // then never go through a staging buffer the runtime would have to find at call time
     // cancellation and presentation
     hipStream_t side_stream = nullptr;  // carries the cancel word and frame snapshots past a render that is still running
     uint32_t* d_cancel = nullptr;       // serial of the cancelled render (kernels compare it with their own)
     uint32_t* h_serial = nullptr;       // pinned: source of the copy into d_cancel
     uint32_t serial = 0;                // serial of the latest render / ray query
     uint8_t* h_frame = nullptr;         // pinned host copy of the frame (rt_engine_map_frame), allocated on first use
-    bool frame_dirty = false;           // the frame buffer changed since the last complete copy into h_frame
+    bool frame_dirty = true;            // the frame buffer differs from h_frame (true from the start: h_frame is allocated uninitialised,
+                                        // and the first complete map must copy the zeroed frame buffer, FrameManager.cpp:13)
     Scene sc{};
     bool have_scene = false, have_camera = false;
     Cam cam{};
@@ -711,7 +715,8 @@ struct rt_engine {
     // statistics of the last render
     std::vector<uint32_t> h_counts;     // per batch: counts (B + 2), cursors (B + 2)
     uint32_t* d_counts_all = nullptr;
-    int counts_capacity = 0, last_batches = 0;
+    size_t counts_capacity = 0;         // words
+    int last_batches = 0;
     uint64_t last_paths = 0;
     bool time_kernels = false;
     std::vector<hipEvent_t> ev;
@@ -834,7 +839,13 @@ int init_engine(rt_engine* e, const rt_config* cfg);
 // caller brought, that stream.
 int wait_all(rt_engine* e) {
     HIP_TRY(hipStreamSynchronize(e->stream));
-    if (e->last_stream) HIP_TRY(hipStreamSynchronize(e->last_stream));
+    if (e->last_stream) {
+        // the caller's handle is used this once and then forgotten: everything queued on it for this engine has finished,
+        // and the caller may destroy the stream from here on
+        hipStream_t st = e->last_stream;
+        e->last_stream = nullptr;
+        HIP_TRY(hipStreamSynchronize(st));
+    }
     return RT_OK;
 }
 
@@ -893,6 +904,7 @@ int init_engine(rt_engine* e, const rt_config* cfg) {
     HIP_TRY(hipHostMalloc((void**)&e->h_serial, 256, hipHostMallocDefault));
     // the engine's device is current (rt_engine_create): the address of this GPU's copy of the staging array
     HIP_TRY(hipGetSymbolAddress((void**)&e->d_scratch, HIP_SYMBOL(scratch)));
+    HIP_TRY(hipHostMalloc((void**)&e->h_stage, sizeof(scratch), hipHostMallocDefault));
     const size_t cap = (size_t)e->q.capacity;
     for (int k = 0; k < 2; k++) {
         // one allocation, b behind a: the camera rays' pass also uses the input queue of the pass after it, empty until
@@ -909,8 +921,13 @@ int init_engine(rt_engine* e, const rt_config* cfg) {
     e->n_counts = cfg->bounces + 2;
     // pass counters for the largest number of batches a render can need (one rank rendering the whole frame), so that
     // rendering never allocates
-    e->counts_capacity = (int)((frame_paths / spp + batch_pixels - 1) / batch_pixels) * COUNT_WORDS;
-    HIP_TRY(hipMalloc((void**)&e->d_counts_all, sizeof(uint32_t) * (size_t)e->counts_capacity));
+    // (COUNT_WORDS words, 135 KB, per batch: a small max_batch_paths on a large frame would ask for gigabytes of counters,
+    // and for more batches than an int counts words of)
+    const long long max_batches = (frame_paths / spp + batch_pixels - 1) / batch_pixels;
+    if (max_batches > MAX_BATCHES)
+        return fail(RT_E_INVALID, "max_batch_paths is too small for this frame: more than " + std::to_string(MAX_BATCHES) + " batches");
+    e->counts_capacity = (size_t)max_batches * COUNT_WORDS;
+    HIP_TRY(hipMalloc((void**)&e->d_counts_all, sizeof(uint32_t) * e->counts_capacity));
     // the staged variants of the intersect kernel may use up to a whole CU's LDS; the limit is a property of the kernel,
     // not of an engine or a scene, so every engine sets the same value
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<true, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
@@ -954,6 +971,7 @@ void rt_engine_destroy(rt_engine* e) {
     (void)hipFree(e->d_cancel);
     if (e->h_serial) (void)hipHostFree(e->h_serial);
     if (e->h_frame) (void)hipHostFree(e->h_frame);
+    if (e->h_stage) (void)hipHostFree(e->h_stage);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -1130,7 +1148,7 @@ int rt_engine_render(rt_engine* e, uint32_t seed, int rank, int n_ranks, uint8_t
     const int batch_pixels = e->q.capacity / spp;
     const int n_batches = (int)((my_pixels + batch_pixels - 1) / batch_pixels);
     const int per_batch = COUNT_WORDS;
-    if (n_batches * per_batch > e->counts_capacity) return fail(RT_E_INVALID, "render needs more batches than the engine was created for");
+    if ((size_t)n_batches * per_batch > e->counts_capacity) return fail(RT_E_INVALID, "render needs more batches than the engine was created for");
     HIP_TRY(hipMemsetAsync(e->d_counts_all, 0, sizeof(uint32_t) * (size_t)n_batches * per_batch, st));
     if (n_ranks > 1) HIP_TRY(hipMemsetAsync(out, 0, (size_t)my_pixels * 4, st));
     e->ev_used = 0;
@@ -1203,6 +1221,18 @@ int rt_engine_read_frame(rt_engine* e, uint8_t* rgba_out) {
     HIP_TRY(hipSetDevice(e->cfg.device));
     if (int rc = wait_all(e)) return rc;
     HIP_TRY(hipMemcpy(rgba_out, e->d_frame, (size_t)e->cfg.width * e->cfg.height * 4, hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+// The pixels [x0,x1) x [y0,y1) of the engine's own frame buffer, rows of (x1 - x0) * 4 bytes one after another: what a
+// caller of World::CalculateColorForScreenPosition (World.cpp:68-102) for a few pixels needs back, without the frame.
+int rt_engine_read_rect(rt_engine* e, int x0, int y0, int x1, int y1, uint8_t* rgba_out) {
+    if (!e || !rgba_out) return fail(RT_E_INVALID, "null argument");
+    if (x0 < 0 || y0 < 0 || x1 > e->cfg.width || y1 > e->cfg.height || x0 >= x1 || y0 >= y1) return fail(RT_E_INVALID, "rectangle must be non-empty and inside the frame");
+    HIP_TRY(hipSetDevice(e->cfg.device));
+    if (int rc = wait_all(e)) return rc;
+    const size_t row = (size_t)(x1 - x0) * 4, pitch = (size_t)e->cfg.width * 4;
+    HIP_TRY(hipMemcpy2D(rgba_out, row, e->d_frame + (size_t)y0 * pitch + (size_t)x0 * 4, pitch, row, (size_t)(y1 - y0), hipMemcpyDeviceToHost));
     return RT_OK;
 }
 
@@ -1333,30 +1363,38 @@ int rt_engine_trace(rt_engine* e, int n, const float* o3, const float* d3, int32
 }
 
 // rt_engine_trace for callers that must not allocate: the rays and the results are staged in this GPU's static array
-// instead of four fresh allocations.  No hipMalloc / hipFree / allocating library call on this path.
+// instead of four fresh allocations, and cross the bus through the engine's page-locked mirror of that array (allocated
+// with the engine), so that the copies are plain DMA transfers.  No hipMalloc / hipFree / allocating library call here.
 int rt_engine_trace_static(rt_engine* e, int n, const float* o3, const float* d3, int32_t* hit_id, float* rec9) {
     if (!e || !o3 || !d3 || !hit_id || !rec9 || n < 0) return fail(RT_E_INVALID, "bad arguments");
     if (!e->have_scene) return fail(RT_E_INVALID, "no scene set");
     if (n > RT_TRACE_STATIC_MAX_RAYS) return fail(RT_E_INVALID, "rt_engine_trace_static takes at most RT_TRACE_STATIC_MAX_RAYS (32768) rays per call");
     if (n == 0) return RT_OK;
     HIP_TRY(hipSetDevice(e->cfg.device));
-    if (!e->d_scratch) return fail(RT_E_DEVICE, "the static staging array was not resolved on this device");
+    if (!e->d_scratch || !e->h_stage) return fail(RT_E_DEVICE, "the static staging array was not resolved on this device");
+    if (int rc = wait_all(e)) return rc;   // like rt_engine_trace: a render on a stream the caller brought has finished
     // fixed sections of the array, sized for the maximum: origins | directions | hit ids | records.  Every byte a call
     // reads was written by the same call (inputs by the copies below, outputs by the kernel for rays 0..n-1), so what an
     // earlier, larger call left behind is never looked at and nothing needs clearing.
+    constexpr size_t AT_D = (size_t)RT_TRACE_STATIC_MAX_RAYS * 12, AT_HIT = (size_t)RT_TRACE_STATIC_MAX_RAYS * 24, AT_REC = (size_t)RT_TRACE_STATIC_MAX_RAYS * 28;
     unsigned char* base = e->d_scratch;
+    unsigned char* host = e->h_stage;
     float* d_o = reinterpret_cast<float*>(base);
-    float* d_d = reinterpret_cast<float*>(base + (size_t)RT_TRACE_STATIC_MAX_RAYS * 12);
-    int32_t* d_hit = reinterpret_cast<int32_t*>(base + (size_t)RT_TRACE_STATIC_MAX_RAYS * 24);
-    float* d_rec = reinterpret_cast<float*>(base + (size_t)RT_TRACE_STATIC_MAX_RAYS * 28);
-    HIP_TRY(hipMemcpyAsync(d_o, o3, (size_t)n * 12, hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipMemcpyAsync(d_d, d3, (size_t)n * 12, hipMemcpyHostToDevice, e->stream));
+    float* d_d = reinterpret_cast<float*>(base + AT_D);
+    int32_t* d_hit = reinterpret_cast<int32_t*>(base + AT_HIT);
+    float* d_rec = reinterpret_cast<float*>(base + AT_REC);
+    memcpy(host, o3, (size_t)n * 12);
+    memcpy(host + AT_D, d3, (size_t)n * 12);
+    HIP_TRY(hipMemcpyAsync(d_o, host, (size_t)n * 12, hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipMemcpyAsync(d_d, host + AT_D, (size_t)n * 12, hipMemcpyHostToDevice, e->stream));
     if (e->sc.has_fog) hipLaunchKernelGGL(trace_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->sc, n, d_o, d_d, d_hit, d_rec);
     else hipLaunchKernelGGL(trace_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->sc, n, d_o, d_d, d_hit, d_rec);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(hit_id, d_hit, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipMemcpyAsync(rec9, d_rec, (size_t)n * 36, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(host + AT_HIT, d_hit, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(host + AT_REC, d_rec, (size_t)n * 36, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    memcpy(hit_id, host + AT_HIT, (size_t)n * 4);
+    memcpy(rec9, host + AT_REC, (size_t)n * 36);
     return RT_OK;
 }
 
@@ -1525,6 +1563,8 @@ struct rt_multi {
     std::vector<rt_engine*> eng;
     std::vector<uint8_t*> d_tiles;      // per engine, on its device: rt_engine_tile_bytes
     std::vector<hipEvent_t> done;       // per engine: its tiles are complete
+    std::vector<hipEvent_t> taken;      // per engine: the display device has copied its tiles (recorded on the display stream)
+    bool rendered = false;              // `taken` events have been recorded at least once
     uint8_t* d_gathered = nullptr;      // on the display device: n packed buffers back to back
     size_t tile_bytes = 0;
 };
@@ -1537,6 +1577,7 @@ void rt_multi_destroy(rt_multi* m) {
         (void)wait_all(m->eng[k]);
         if (k < m->d_tiles.size()) (void)hipFree(m->d_tiles[k]);
         if (k < m->done.size() && m->done[k]) (void)hipEventDestroy(m->done[k]);
+        if (k < m->taken.size() && m->taken[k]) (void)hipEventDestroy(m->taken[k]);
     }
     if (!m->eng.empty() && m->eng[0]) { (void)hipSetDevice(m->eng[0]->cfg.device); (void)hipFree(m->d_gathered); }
     for (rt_engine* e : m->eng) rt_engine_destroy(e);
@@ -1550,6 +1591,7 @@ int rt_multi_create(const rt_config* cfg, const int32_t* device_ids, int n_dev, 
         m->eng.assign((size_t)n_dev, nullptr);
         m->d_tiles.assign((size_t)n_dev, nullptr);
         m->done.assign((size_t)n_dev, nullptr);
+        m->taken.assign((size_t)n_dev, nullptr);
         for (int k = 0; k < n_dev; k++) {
             rt_config c = *cfg;
             c.device = device_ids[k];
@@ -1563,6 +1605,7 @@ int rt_multi_create(const rt_config* cfg, const int32_t* device_ids, int n_dev, 
             }
             if (int rc = rt_engine_create(&c, &m->eng[k])) { rt_multi_destroy(m); return rc; }
             hipError_t he = hipEventCreateWithFlags(&m->done[k], hipEventDisableTiming);
+            if (he == hipSuccess) he = hipEventCreateWithFlags(&m->taken[k], hipEventDisableTiming);
             if (he == hipSuccess && n_dev > 1) {
                 m->tile_bytes = (size_t)rt_engine_tile_bytes(m->eng[k], n_dev);
                 he = hipMalloc((void**)&m->d_tiles[k], m->tile_bytes);
@@ -1593,12 +1636,19 @@ int rt_multi_set_camera(rt_multi* m, const float cam12[12]) {
     return RT_OK;
 }
 // One frame into the display engine's own frame buffer (rt_multi_map_frame / rt_engine_read_frame on engine 0 hand it out).
+// Frames may be queued one behind the other without a wait in between.  What keeps them apart: engine k's packed tiles
+// are written by its render on its own stream and read by the copy on the display stream, so (1) the copy waits for the
+// render's event `done[k]`, and (2) the NEXT render of engine k — which begins by zeroing that same buffer — waits for the
+// event `taken[k]` recorded on the display stream behind the copy.  The gathered buffer and the frame buffer are only
+// touched on the display stream (copies, then the scatter), which orders them by itself.
 int rt_multi_render(rt_multi* m, uint32_t frame_seed) {
     if (!m) return fail(RT_E_INVALID, "null handle");
     const int n = (int)m->eng.size();
     if (n == 1) return rt_engine_render(m->eng[0], frame_seed, 0, 1, nullptr, nullptr);
     for (int k = 0; k < n; k++) {
         rt_engine* e = m->eng[k];
+        HIP_TRY(hipSetDevice(e->cfg.device));
+        if (m->rendered && k > 0) HIP_TRY(hipStreamWaitEvent(e->stream, m->taken[k], 0));   // (engine 0 renders on the display stream itself)
         if (int rc = rt_engine_render(e, frame_seed, k, n, m->d_tiles[k], nullptr)) return rc;
         HIP_TRY(hipEventRecord(m->done[k], e->stream));     // the engine's device is current after rt_engine_render
     }
@@ -1610,7 +1660,9 @@ int rt_multi_render(rt_multi* m, uint32_t frame_seed) {
         uint8_t* dst = m->d_gathered + (size_t)k * m->tile_bytes;
         if (e->cfg.device == d->cfg.device) HIP_TRY(hipMemcpyAsync(dst, m->d_tiles[k], m->tile_bytes, hipMemcpyDeviceToDevice, d->stream));
         else HIP_TRY(hipMemcpyPeerAsync(dst, d->cfg.device, m->d_tiles[k], e->cfg.device, m->tile_bytes, d->stream));
+        if (k > 0) HIP_TRY(hipEventRecord(m->taken[k], d->stream));
     }
+    m->rendered = true;
     return rt_engine_assemble(d, m->d_gathered, n, nullptr, nullptr);
 }
 int rt_multi_poll(rt_multi* m) {

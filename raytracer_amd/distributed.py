@@ -53,7 +53,9 @@ class TileRenderer:
 
     def render_frame(self, seed):
         """Enqueue one frame.  Returns the frame tensor (H*W*4 bytes) on the display rank, None elsewhere; with several
-        frames in flight the tensor belongs to the frame's slot and is overwritten when its turn comes again."""
+        frames in flight the tensor belongs to the frame's slot and is overwritten when its turn comes again.  The frame
+        is rendered on a stream of the slot's own; the caller's current stream is made to wait for it, so work queued on
+        that stream afterwards sees the finished frame."""
         slot = self.slots[self.turn]
         self.turn = (self.turn + 1) % len(self.slots)
         if slot.stream is None:
@@ -61,6 +63,10 @@ class TileRenderer:
         else:
             with torch.cuda.stream(slot.stream):
                 out = self._render_frame(slot, seed)
+            # the frame is written on the slot's stream: whatever the caller queues next on ITS current stream (a copy
+            # of the returned tensor, say) waits for it on the GPU; the host does not wait, and the other slots' streams
+            # are not held up
+            torch.cuda.current_stream(self.device).wait_stream(slot.stream)
         if out is not None:
             self.frame = out
         return out

@@ -90,6 +90,7 @@ SIGNATURES = {
     "rt_engine_sync": (C.c_int, [_V]),
     "rt_engine_poll": (C.c_int, [_V]),
     "rt_engine_read_frame": (C.c_int, [_V, u8p]),
+    "rt_engine_read_rect": (C.c_int, [_V, C.c_int, C.c_int, C.c_int, C.c_int, u8p]),
     "rt_engine_map_frame": (C.c_int, [_V, C.c_int, _PV]),
     "rt_engine_clear_frame": (C.c_int, [_V, _V]),
     "rt_engine_cancel": (C.c_int, [_V]),
@@ -382,6 +383,12 @@ class Engine:
     def read_frame(self):
         out = np.zeros((self.cfg.height, self.cfg.width, 4), np.uint8)
         _check(self.L.rt_engine_read_frame(self.h, out))
+        return out
+
+    def read_rect(self, x0, y0, x1, y1):
+        """the pixels [x0,x1) x [y0,y1) of the engine's own frame buffer"""
+        out = np.zeros((y1 - y0, x1 - x0, 4), np.uint8)
+        _check(self.L.rt_engine_read_rect(self.h, x0, y0, x1, y1, out))
         return out
 
     def render_frame(self, seed):

@@ -450,6 +450,63 @@ def test_several_devices_behind_one_handle(rt, gpu_default, ids):
     assert_bits(m.map_frame(wait=True), base, "frame after a cancelled one")
 
 
+def test_frames_queued_back_to_back_on_several_devices(rt, gpu_default):
+    """rt_multi_render three times with no wait in between, a different seed each time: a device's next render zeroes and
+    refills the packed tiles the display device still has to copy for the frame before, so it must wait for that copy on
+    the GPU.  Large enough that every render is still running when the next one is queued; the last frame is checked."""
+    W, H, S, B = 1920, 1080, 4, 6
+    cam = rt.camera_look(CAM_POS, CAM_LOOK)
+    one = make_engine(rt, gpu_default, W, H, S, B, cam)
+    want = {seed: one.render_frame(seed) for seed in (31, 32, 33)}
+    one.close()
+    assert (want[32] != want[33]).any()
+    m = rt.MultiEngine(rt.default_config(width=W, height=H, samples_per_axis=S, bounces=B), [0, 0, 0])
+    m.set_scene(gpu_default)
+    m.set_camera(cam)
+    for seed in (31, 32, 33):
+        m.render(seed)
+    assert_bits(m.map_frame(wait=True), want[33], "third of three frames queued back to back")
+    for seed in (33, 31, 32):                      # and once more, starting while nothing is in flight
+        m.render(seed)
+    assert_bits(m.map_frame(wait=True), want[32], "sixth frame")
+
+
+def test_tile_renderer_frame_is_ordered_for_the_callers_stream(rt, gpu_default):
+    """TileRenderer renders on a stream of its own; a copy the caller queues on the current stream right after
+    render_frame (no synchronize in between) must see the finished frame"""
+    import torch
+    from raytracer_amd.distributed import TileRenderer
+    W, H, S, B = 1920, 1080, 4, 6                  # several milliseconds of rendering
+    e = make_engine(rt, gpu_default, W, H, S, B)
+    want = e.render_frame(41)
+    tr = TileRenderer(e, "cuda:0")
+    host = torch.empty(H * W * 4, dtype=torch.uint8, pin_memory=True)
+    for seed in (40, 41):
+        frame = tr.render_frame(seed)
+        host.copy_(frame, non_blocking=True)       # on the current stream, straight behind the call
+    torch.cuda.current_stream().synchronize()
+    assert_bits(host.numpy().reshape(H, W, 4), want, "frame copied on the caller's stream without a device-wide wait")
+
+
+def test_host_frame_before_any_render_and_single_pixels(rt, gpu_default):
+    """FrameManager hands out its zeroed texturePixels before the first frame has started (FrameManager.cpp:13,60-71); a
+    caller of World::CalculateColorForScreenPosition gets a pixel's bytes without the frame around it"""
+    W, H, S, B = 320, 180, 2, 3
+    e = make_engine(rt, gpu_default, W, H, S, B)
+    assert not e.map_frame(wait=True).any(), "the frame before any render must be zero"
+    frame = e.render_frame(5)
+    assert_bits(e.read_rect(17, 40, 18, 41), frame[40:41, 17:18], "one pixel")
+    assert_bits(e.read_rect(300, 100, 320, 180), frame[100:180, 300:320], "a rectangle up to the frame's corner")
+    e.set_window((17, 40, 18, 41))                 # the adapter's CalculateColorForScreenPosition
+    e.clear_frame()
+    e.render(5)
+    assert_bits(e.read_rect(17, 40, 18, 41), frame[40:41, 17:18], "one pixel rendered on its own")
+    with pytest.raises(rt.RtError):
+        e.read_rect(0, 0, W + 1, 1)
+    with pytest.raises(rt.RtError):                # 64-pixel batches of a 4K frame: more pass counters than an engine reserves
+        rt.Engine(rt.default_config(width=3840, height=2160, samples_per_axis=1, bounces=1, max_batch_paths=64))
+
+
 def test_front_end_adapter_matches_the_c_abi(rt, gpu_default, tmp_path):
     """raytracer_amd/compat_demo drives the FrameManager / World / Camera adapter (raytracer_amd/csrc/compat, the
     reference's class interface over the C ABI) like the reference's main loop, at the resolution and quality of the
@@ -864,6 +921,23 @@ def test_c3_full_frame_properties(rt, golden, c3_scene):
     assert (a[..., 0] == 255).all()
     x0, y0, x1, y1 = (int(v) for v in g["crop"])
     assert_frame_close(a[y0:y1, x0:x1], g["crop_rgba"], "C3 full frame, crop region vs the reference")
+    # C4 at its real size: the frame as the eight shares of an 8-GPU node (tiles interleaved, two batches of 2^27 paths
+    # per share), every share rendered here on the one GPU into its place in the gathered buffer, then scattered
+    import torch
+    n_ranks = 8
+    nb = e.tile_bytes(n_ranks)
+    gathered = torch.zeros(n_ranks * nb, dtype=torch.uint8, device="cuda")
+    share = []
+    for r in range(n_ranks):
+        e.render(seed, rank=r, n_ranks=n_ranks, d_out=gathered.data_ptr() + r * nb)
+        share.append(e.stats()["rays"])
+    out = torch.zeros(H * W * 4, dtype=torch.uint8, device="cuda")
+    e.assemble(gathered.data_ptr(), n_ranks, d_out=out.data_ptr())
+    e.sync()
+    assert_bits(out.cpu().numpy().reshape(H, W, 4), a, "C4: eight shares of the full-size frame, assembled")
+    assert sum(share) == st["rays"], "C4: the shares' rays add up to the frame's"
+    assert max(share) < 1.1 * st["rays"] / n_ranks, f"C4 shares {share}: interleaved tiles should balance within 10 %"
+    del gathered, out
     e.set_window((1800, 1000, 2056, 1128))
     c = e.render_frame(seed)
     assert_bits(c[1000:1128, 1800:2056], a[1000:1128, 1800:2056], "C3 window vs full frame")

@@ -56,3 +56,42 @@ def test_asset_decoders_on_every_reference_asset(rt, ref):
             assert_bits(got, want, f"{name} decoded to {channels} channels")
     for name in ("Rock.obj", "tree.obj"):
         assert_bits(E.load_obj(os.path.join(REF_ASSETS, name)), ref.load_obj(os.path.join(REF_ASSETS, name)), f"{name} vertices")
+
+
+ODD_OBJ = (
+    "# records the reference's parser reads in its own way\r\n"
+    "v 0 0 0\r\n"
+    "v 1.5e0 0 0 2\n"
+    "\tv   0 +1 .5\n"
+    "v -1 1e 7 8\n"                 # "1e" is not a number: y = 0 and the record ends (z keeps 0)
+    "v 2 abc 3\n"                   # y = 0, z stays 0
+    "v 3\n"                         # y, z missing
+    "v 0.1 0.2 0.30000001192092896 trailing\n"
+    "v 1e-3 -2.5E+1 1.e1\n"
+    "v 4 - 5\n"
+    "vt 0.25 0.75\n"
+    "vt 1 0 0\n"
+    "vt .5\n"
+    "vn 0 0 2\n"
+    "vn 1 1 0\n"
+    "vn 0 3\n"
+    "f 1/1/1 2/2/2 3/3/3\n"
+    "f 1 2 3\n"                     # no texture coordinate, no normal: the face normal
+    "f 1//2 2//2 3//2 4//2 5//2\n"  # a fan of three triangles
+    "f -1/-1/-1 -2/-2/-2 -3/-3/-3\n"
+    "f 6/1x/2 7/+2/3 8/3/1junk\n"
+    "f 1/1/1 2/2/2\n"               # two corners: nothing
+    "vn 0 0 0\n"                    # normalises to NaN
+    "f 9/1/4 1/1/1 2/2/2\n"
+    "g ignored 1 2 3\n"
+    "f 3/3/3 2/2/2 1/1/1")          # no newline at the end
+
+
+def test_obj_parser_on_odd_records(rt, ref, tmp_path):
+    """fields that are missing, malformed, signed, relative, or separated by tabs and carriage returns: the product's
+    tokenizer must hand out what LoadOBJ (Object.cpp:349-435: stream extraction, getline on '/', atoi) hands out"""
+    path = tmp_path / "odd.obj"
+    path.write_bytes(ODD_OBJ.encode())
+    got, want = rt.engine.load_obj(str(path)), ref.load_obj(str(path))
+    assert len(want) == 3 * 9
+    assert_bits(got, want, "odd OBJ records")
