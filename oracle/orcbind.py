@@ -83,6 +83,7 @@ def lib():
     L.orc_thread_pixel_order.restype = C.c_int
     L.orc_thread_pixel_order.argtypes = [C.c_int] * 6 + [u32p]
     L.orc_counters.argtypes = [C.c_void_p, u64p, C.c_int]
+    L.orc_repeat_counters.argtypes = [C.c_void_p, u64p]
     L.orc_rand31.restype = C.c_uint32
     L.orc_rand31.argtypes = [C.c_uint32, C.c_uint32]
     L.orc_sample_key.restype = C.c_uint32
@@ -258,6 +259,12 @@ class Scene:
     def counters(self, reset=False):
         out = np.zeros(16, np.uint64)
         self.L.orc_counters(self.h, out, int(reset))
+        return dict(zip(COUNTER_NAMES, (int(v) for v in out)))
+
+    def repeat_counters(self):
+        """the part of counters() spent on second visits of leaves listed as both children of a node (Object.cpp:198-200)"""
+        out = np.zeros(16, np.uint64)
+        self.L.orc_repeat_counters(self.h, out)
         return dict(zip(COUNTER_NAMES, (int(v) for v in out)))
 
 

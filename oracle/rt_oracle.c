@@ -47,10 +47,11 @@ struct orc_scene {
     int math_mode;
     int next_id;
     uint64_t counters[C_COUNT];
+    uint64_t repeats[C_COUNT];   /* the part of `counters` spent on the second visit of a leaf listed as both children */
     pthread_mutex_t lock;
 };
 
-typedef struct { const orc_scene* s; uint32_t key, ctr; uint64_t cnt[C_COUNT]; float sky_brightness; } Ctx;
+typedef struct { const orc_scene* s; uint32_t key, ctr; uint64_t cnt[C_COUNT]; float sky_brightness; uint64_t rep[C_COUNT]; int in_repeat; } Ctx;
 
 /* ------------------------------------------------------------------------------------------------------------
  * keyed counter RNG standing in for std::rand (DataUtility.h:11-12), RAND_MAX = 2^31-1 as on glibc
@@ -379,7 +380,18 @@ static int node_hit(Ctx* c, const Obj* o, const Ray* ray, Hit* hi) {
     Hit info2;
     memset(&info2, 0, sizeof info2);
     info2.object = -1; info2.distance = FLT_MAX;
-    int hit_right = obj_hit(c, o->right, ray, &info2);
+    int hit_right;
+    if (o->right == o->left && !c->in_repeat) {
+        /* a node over one object has it as both children (Object.cpp:198-200): the reference does everything below it a
+         * second time.  The events of that second visit are also booked apart, so that a traversal which lists such a
+         * leaf once can be priced by the work it executes. */
+        uint64_t before[C_COUNT];
+        memcpy(before, c->cnt, sizeof before);
+        c->in_repeat = 1;
+        hit_right = obj_hit(c, o->right, ray, &info2);
+        c->in_repeat = 0;
+        for (int i = 0; i < C_COUNT; i++) c->rep[i] += c->cnt[i] - before[i];
+    } else hit_right = obj_hit(c, o->right, ray, &info2);
     if (hit_right && (!hit_left || (hit_left && info2.distance < hi->distance))) *hi = info2;
     return hit_left || hit_right;
 }
@@ -955,7 +967,7 @@ static void cfg_init(Cfg* g, const int* ci, const float* cf, const float* cam) {
 }
 static void merge_counters(orc_scene* s, const Ctx* c) {
     pthread_mutex_lock(&s->lock);
-    for (int i = 0; i < C_COUNT; i++) s->counters[i] += c->cnt[i];
+    for (int i = 0; i < C_COUNT; i++) { s->counters[i] += c->cnt[i]; s->repeats[i] += c->rep[i]; }
     pthread_mutex_unlock(&s->lock);
 }
 
@@ -1107,7 +1119,12 @@ void orc_skybox(orc_scene* s, int n, const float* d3, float* rgb) {
 }
 void orc_counters(orc_scene* s, uint64_t* out15, int reset) {
     pthread_mutex_lock(&s->lock);
-    for (int i = 0; i < C_COUNT; i++) { out15[i] = s->counters[i]; if (reset) s->counters[i] = 0; }
+    for (int i = 0; i < C_COUNT; i++) { out15[i] = s->counters[i]; if (reset) { s->counters[i] = 0; s->repeats[i] = 0; } }
+    pthread_mutex_unlock(&s->lock);
+}
+void orc_repeat_counters(orc_scene* s, uint64_t* out16) {
+    pthread_mutex_lock(&s->lock);
+    for (int i = 0; i < C_COUNT; i++) out16[i] = s->repeats[i];
     pthread_mutex_unlock(&s->lock);
 }
 

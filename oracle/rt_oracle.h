@@ -90,6 +90,9 @@ void orc_render_framemanager(orc_scene*, const int* cfg_i, const float* cfg_f, c
  * rays, aabb, sph_test, sph_hit, cube_test, cube_hit, plane_test, plane_hit, tri_test, tri_uv, inst_enter, inst_hit,
  * samples, shade, rng */
 void orc_counters(orc_scene*, uint64_t* out16, int reset);
+/* the part of those counters that was spent on the second visit of a leaf the reference lists as both children of a node
+ * (Object.cpp:198-200, 241-252): work a traversal that lists such a leaf once does not repeat.  Reset with orc_counters. */
+void orc_repeat_counters(orc_scene*, uint64_t* out16);
 float orc_pm_logf(float x);
 
 /* RNG and portable math, exposed for known-answer tests */
