@@ -61,6 +61,10 @@ typedef struct rt_config {
  * it from device memory as it reads large scenes — the same results through the other variant of the kernel, for
  * comparisons and tests. */
 #define RT_FLAG_NO_LDS 2
+/* A scene that is read from device memory is walked near side first, the children a ray has yet to visit on a stack in
+ * on-chip memory; this flag makes the kernel take the children in the reference's order, without a stack — the same
+ * results through the other variant of the kernel, for comparisons and tests. */
+#define RT_FLAG_NO_ORDER 4
 void rt_config_defaults(rt_config* cfg);   /* the values of Constants.h:4-17 */
 
 /* ---------------------------------------------------------------------------------------------------------

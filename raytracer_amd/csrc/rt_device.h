@@ -162,6 +162,14 @@ struct Scene {
     float cull_delta, cull_cabs, cull_2rmax;
     int cull_on;
 };
+// What the ordered traversal (see "ordered traversal" below) needs beside the scene; ent_ord == nullptr: the scene has none
+struct OrdScene {
+    const float4* ent_ord;        // the entries with second-child links in place of skip links
+    const uint32_t* top_tab;      // records of the tree's upper levels, copied into LDS by every block
+    const int32_t* inst_end;      // per instance: the END entry that closes its range
+    int n_top_tab, stack_slots;   // records in top_tab; stack slots a ray can need
+    uint32_t root_link;           // where a ray starts: entry 0, or its record in the table
+};
 struct Ray { V3 o, d; };
 
 // BoundingBox::DoesRayHit (DataUtility.cpp:35-82): true division per axis, branch on dir >= 0 (so -0.0 takes the >= branch),
@@ -412,9 +420,18 @@ struct Walker {
     float reach;                // > 0: the ray reaches the triangle f0 at this distance and tri_surface has yet to run
     Rng rng;                    // the path's random stream: fog volumes draw from it during traversal
     Closest c;
+    // ordered traversal only: LDS byte address of the lane's next free stack slot; first-child link of the table record
+    // the lane stands on
+    uint32_t sp, eleft;
 };
 // entries (and, when staged, triangles) either in LDS or in global memory
-struct Store { const float4* ent; const float4* tris; const float4* inst; const float4* planes; };   // 2 x float4 per entry
+struct Store {
+    const float4* ent; const float4* tris; const float4* inst; const float4* planes;   // 2 x float4 per entry
+    // ordered traversal only: the block's dynamic LDS as dwords and its LDS byte address; byte addresses of the table of
+    // upper-level records and of slot 0 of thread 0's stack
+    uint32_t* lds0; uint32_t lds0_addr, top_addr, stack_addr;
+    uint32_t root_link; const int32_t* inst_end;   // where a ray starts; per instance the END entry that closes its range
+};
 
 __device__ __forceinline__ Ray walker_ray(const Walker& w) {
     Ray r;
@@ -791,6 +808,222 @@ __device__ __forceinline__ void box_steps(const Store& st, Walker& w, int quorum
     RT_PROF(prof.box_iters += box_iters; prof.box_lanes += box_lanes;)
 }
 
+// ---------------------------------------------------------------------------------------------------- ordered traversal
+// For scenes that are read from memory (no fog).  The reference takes a node's children in the order it stored them
+// and, having no limit on the distance, descends into both.  Distance culling (above) prunes the boxes that lie behind
+// the closest hit — the more the sooner a close hit is found.  This traversal therefore visits the child on the ray's
+// near side first: the children of a node were ordered by their boxes' minimum along the node's axis, so the first
+// child is the near one when the ray's direction component along that axis is not negative.  The other child waits on
+// a per-lane stack in LDS (slot s of thread t at dword s * BLOCK + t: conflict-free), and a lane that misses a box or
+// notes a leaf continues with what it pops.  The boxes a ray tests are still a subset of the reference's and every one
+// of them is decided as the reference decides it; what changes is the order in which leaves are met, which the
+// reference's result depends on in exactly two places, both restated in closest_update:
+//   * equal distances: BVH_Node::Intersect keeps the hit it met first (Object.cpp:248, strict <).  Entries are numbered
+//     in the reference's visiting order, so of two leaves at the same distance the one with the smaller rank wins;
+//   * the first leaf's rejected HitInfo.distance survives only if nothing is hit at all: it is recorded only while the
+//     ray has no hit, and any hit overwrites it.
+// A culled box holds no leaf that could tie (the bound is strict), so culling and ordering do not interact.
+// The records of the tree's upper levels (most of the 160 KB that the stacks leave) are copied into LDS by every block:
+// steps on them cost no memory access.  A link with LINK_LDS set names such a record; its first child is named in the
+// record (eleft), an entry's first child is the next entry.  Slot 0 of every stack holds the END entry of the top-level
+// list, so the pop after the last subtree ends the walk; entering a mesh instance pushes the END entry of its range.
+__device__ __forceinline__ void ord_push(const Store& st, Walker& w, uint32_t link, uint32_t stride) {
+    st.lds0[(w.sp - st.lds0_addr) >> 2] = link;
+    w.sp += stride;
+}
+__device__ __forceinline__ uint32_t ord_pop(const Store& st, Walker& w, uint32_t stride) {
+    w.sp -= stride;
+    return st.lds0[(w.sp - st.lds0_addr) >> 2];
+}
+__device__ __forceinline__ void walker_load_ord(const Store& st, Walker& w) {
+    const uint32_t i = (uint32_t)w.i;
+    if (i & rt::LINK_LDS) {
+        const uint32_t* e = st.lds0 + ((st.top_addr - st.lds0_addr) >> 2) + rt::TOP_REC_DWORDS * (i & rt::LINK_INDEX);
+        w.e01 = f2{__uint_as_float(e[0]), __uint_as_float(e[1])}; w.e23 = f2{__uint_as_float(e[2]), __uint_as_float(e[3])};
+        w.e45 = f2{__uint_as_float(e[4]), __uint_as_float(e[5])};
+        w.sk = e[6]; w.rho = __uint_as_float(e[7]); w.eleft = e[8];
+    } else walker_load(st, w);
+}
+template <bool CULL, int BLOCK>
+__device__ __forceinline__ void walker_start_ord(const Scene& sc, const Store& st, Walker& w, const Ray ray, const Rng rng) {
+    w.rng = rng;
+    walker_set_ray(w, ray, sc.fast_div_ok != 0);
+    cull_start<CULL>(sc, w, ray);
+    w.i = (int)st.root_link; w.resume = 0; w.inst = -1; w.stale = sc.stale_entry; w.alpha_off = -1; w.alpha_wh = 0;
+    w.f0 = 0; w.f1 = 0; w.f2 = 0; w.cnt = 0; w.reach = 0.0f;
+    w.c.dist = FLT_MAX; w.c.best = -1; w.c.u = 0; w.c.v = 0; w.c.hit = false;
+    w.sp = st.stack_addr + 4u * ((uint32_t)BLOCK + threadIdx.x);     // slot 1: slot 0 holds the end of the top-level list
+    walker_load_ord(st, w);
+}
+// Does leaf entry a come before leaf entry b in the reference's visiting order?  Top-level entries are numbered in that
+// order; a triangle is visited when its mesh's entry is.
+__device__ inline bool rank_before(const Scene& sc, int a, int b) {
+    auto top_of = [&](int e) {
+        if (e < sc.top_end) return e;
+        const int inst = __float_as_int(sc.ent[2 * (size_t)e + 1].w);                            // triangle (or fog) entry: its instance
+        return inst >= 0 ? __float_as_int(sc.inst[(size_t)inst * rt::RT_INST_F4 + 2].w) - 1 : e;   // the instance's own entry
+    };
+    const int ta = top_of(a), tb = top_of(b);
+    return ta != tb ? ta < tb : a < b;
+}
+// The traversal loop of the ordered traversal: box_steps (above) with the stack in place of the skip links, and with
+// the entry fetched from the LDS table or from memory, whichever the link says.  Per iteration, for the lanes that act:
+//   * lanes on an inner entry: the slab test and the culling bound as in box_steps; on a hit the far child is pushed
+//     (if there are two) and the lane goes to the near one, otherwise it pops;
+//   * lanes on a leaf with room in their FIFO: note it, pop;
+//   * both: fetch the entry they stand on now.
+// `signs`: bit k of a lane is set when component k of its ray's direction is negative.
+template <int BLOCK>
+__device__ __forceinline__ void box_steps_ord(const Store& st, Walker& w, int quorum, uint32_t& n_box) {
+    const unsigned long long px = __ballot(w.p3.x >= 0), py = __ballot(w.p3.y >= 0), pz = __ballot(w.p4.x >= 0);
+    const unsigned long long usable = __ballot(w.usable);
+    const uint32_t signs = (w.p3.x >= 0 ? 0u : 1u) | (w.p3.y >= 0 ? 0u : 2u) | (w.p4.x >= 0 ? 0u : 4u);
+    unsigned long long m, m2, m3, m4, mall, saved, mlds, mhit, mpop;
+    int n_inner;
+    uint32_t nb = 0;
+    const float4* base = st.ent;
+    const uint32_t ldsbase = st.top_addr;
+    asm volatile(
+             "s_mov_b64 %[saved], exec\n\t"
+             "1:\n\t"
+             "v_cmp_le_u32_e32 vcc, 0x4000000, %[i]\n\t"
+             "s_mov_b64 %[mlds], vcc\n\t"
+             "v_cmp_gt_u32_e32 vcc, 0x10000000, %[sk]\n\t"
+             "s_and_b64 %[m], vcc, %[usable]\n\t"
+             "v_add_u32_e32 v9, 0xf0000000, %[sk]\n\t"
+             "v_cmp_gt_u32_e64 %[m2], 3, %[cnt]\n\t"
+             "v_cmp_gt_u32_e32 vcc, 0x40000000, v9\n\t"
+             "s_and_b64 %[m2], %[m2], vcc\n\t"
+             "s_or_b64 %[mall], %[m], %[m2]\n\t"
+             "s_cmp_eq_u64 %[mall], 0\n\t"
+             "s_cbranch_scc1 2f\n\t"
+             "s_mov_b64 %[mpop], 0\n\t"
+             "s_cmp_eq_u64 %[m], 0\n\t"
+             "s_cbranch_scc1 3f\n\t"
+             "s_and_b64 exec, %[saved], %[m]\n\t"
+             "v_pk_add_f32 v[10:11], %[e01], %[p0] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+             "v_pk_add_f32 v[12:13], %[e23], %[p0] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+             "v_pk_add_f32 v[14:15], %[e45], %[p1] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+             "v_pk_mul_f32 v[2:3], v[10:11], %[p1] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+             "v_pk_mul_f32 v[4:5], v[12:13], %[p2] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+             "v_pk_mul_f32 v[6:7], v[14:15], %[p2] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+             "v_cndmask_b32_e64 v8, v3, v2, %[px]\n\t"
+             "v_cndmask_b32_e64 v3, v2, v3, %[px]\n\t"
+             "v_cndmask_b32_e64 v2, v5, v4, %[py]\n\t"
+             "v_cndmask_b32_e64 v5, v4, v5, %[py]\n\t"
+             "v_cndmask_b32_e64 v4, v7, v6, %[pz]\n\t"
+             "v_cndmask_b32_e64 v7, v6, v7, %[pz]\n\t"
+             "v_max3_f32 v8, v8, v2, v4\n\t"
+             "v_min3_f32 v3, v3, v5, v7\n\t"
+             "v_fma_f32 v5, %[ck], %[rho], %[cbase]\n\t"
+             "v_cmp_le_f32_e32 vcc, v8, v3\n\t"
+             "v_cmp_nlt_f32_e64 %[m3], v3, 0\n\t"
+             "v_cmp_ngt_f32_e64 %[m4], v8, v5\n\t"
+             "v_sub_u32_e32 v9, v3, v8\n\t"
+             "s_and_b64 vcc, vcc, %[m3]\n\t"
+             "v_add_u32_e32 v9, 32, v9\n\t"
+             "v_add_u32_e32 v4, 1, %[i]\n\t"
+             "v_cmp_gt_u32_e64 %[m3], 64, v9\n\t"
+             "s_cmp_eq_u64 %[m3], 0\n\t"
+             "s_cbranch_scc1 5f\n\t"
+             "v_pk_mul_f32 v[2:3], v[10:11], %[p1] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+             "v_pk_mul_f32 v[4:5], v[12:13], %[p2] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+             "v_pk_mul_f32 v[6:7], v[14:15], %[p2] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+             "v_pk_fma_f32 %[e01], %[p3], v[2:3], v[10:11] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+             "v_pk_fma_f32 %[e23], %[p3], v[4:5], v[12:13] op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+             "v_pk_fma_f32 %[e45], %[p4], v[6:7], v[14:15] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+             "v_pk_fma_f32 v[2:3], %[e01], %[p1], v[2:3] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+             "v_pk_fma_f32 v[4:5], %[e23], %[p2], v[4:5] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+             "v_pk_fma_f32 v[6:7], %[e45], %[p2], v[6:7] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+             "v_pk_fma_f32 %[e01], %[p3], v[2:3], v[10:11] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+             "v_pk_fma_f32 %[e23], %[p3], v[4:5], v[12:13] op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+             "v_pk_fma_f32 %[e45], %[p4], v[6:7], v[14:15] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+             "v_pk_fma_f32 v[2:3], %[e01], %[p1], v[2:3] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+             "v_pk_fma_f32 v[4:5], %[e23], %[p2], v[4:5] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+             "v_pk_fma_f32 v[6:7], %[e45], %[p2], v[6:7] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+             "v_cndmask_b32_e64 v8, v3, v2, %[px]\n\t"
+             "v_cndmask_b32_e64 v3, v2, v3, %[px]\n\t"
+             "v_cndmask_b32_e64 v2, v5, v4, %[py]\n\t"
+             "v_cndmask_b32_e64 v5, v4, v5, %[py]\n\t"
+             "v_cndmask_b32_e64 v4, v7, v6, %[pz]\n\t"
+             "v_cndmask_b32_e64 v7, v6, v7, %[pz]\n\t"
+             "v_max3_f32 v8, v8, v2, v4\n\t"
+             "v_min3_f32 v3, v3, v5, v7\n\t"
+             "v_cmp_le_f32_e32 vcc, v8, v3\n\t"
+             "v_cmp_nlt_f32_e64 %[m3], v3, 0\n\t"
+             "v_add_u32_e32 v4, 1, %[i]\n\t"
+             "s_and_b64 vcc, vcc, %[m3]\n\t"
+             "5:\n\t"
+             "s_and_b64 %[mhit], vcc, %[m4]\n\t"                    // box hit and not culled (zero outside the acting lanes)
+             "v_and_b32_e32 v2, 3, %[rho]\n\t"                      // axis; 3 = a single child
+             "v_lshrrev_b32_e32 v3, v2, %[signs]\n\t"
+             "v_and_b32_e32 v3, 1, v3\n\t"                          // 1: the direction is negative along the axis
+             "v_cndmask_b32_e64 v5, v4, %[eleft], %[mlds]\n\t"      // first child: the next entry, or what the table record says
+             "v_cmp_eq_u32_e32 vcc, 1, v3\n\t"
+             "v_cndmask_b32_e32 v6, v5, %[sk], vcc\n\t"             // near child (an inner entry's dword 6 IS its second child's link)
+             "v_cndmask_b32_e32 v7, %[sk], v5, vcc\n\t"             // far child
+             "v_cmp_ne_u32_e32 vcc, 3, v2\n\t"
+             "s_and_b64 vcc, vcc, %[mhit]\n\t"
+             "s_mov_b64 exec, vcc\n\t"                              // hit, two children: the far one waits on the stack
+             "ds_write_b32 %[sp], v7\n\t"
+             "v_add_u32_e32 %[sp], %[stride], %[sp]\n\t"
+             "s_mov_b64 exec, %[mhit]\n\t"
+             "v_mov_b32_e32 %[i], v6\n\t"
+             "s_andn2_b64 %[mpop], %[m], %[mhit]\n\t"               // missed or culled: pop
+             "3:\n\t"
+             "s_cmp_eq_u64 %[m2], 0\n\t"
+             "s_cbranch_scc1 4f\n\t"
+             "s_and_b64 exec, %[saved], %[m2]\n\t"
+             "v_cmp_eq_u32_e64 %[m3], 0, %[cnt]\n\t"
+             "v_cmp_eq_u32_e32 vcc, 1, %[cnt]\n\t"
+             "v_mov_b32_e32 %[f2], %[i]\n\t"
+             "v_add_u32_e32 %[cnt], 1, %[cnt]\n\t"
+             "v_cndmask_b32_e64 %[f0], %[f0], %[i], %[m3]\n\t"
+             "v_cndmask_b32_e32 %[f1], %[f1], %[i], vcc\n\t"
+             "s_or_b64 %[mpop], %[mpop], %[m2]\n\t"
+             "4:\n\t"
+             "s_cmp_eq_u64 %[mpop], 0\n\t"
+             "s_cbranch_scc1 6f\n\t"
+             "s_mov_b64 exec, %[mpop]\n\t"
+             "v_subrev_u32_e32 %[sp], %[stride], %[sp]\n\t"
+             "ds_read_b32 %[i], %[sp]\n\t"
+             "s_waitcnt lgkmcnt(0)\n\t"
+             "6:\n\t"
+             "s_and_b64 exec, %[saved], %[mall]\n\t"
+             "v_cmp_le_u32_e32 vcc, 0x4000000, %[i]\n\t"            // which of the new entries are table records
+             "s_andn2_b64 exec, exec, vcc\n\t"
+             "v_lshlrev_b32_e32 v2, 5, %[i]\n\t"
+             "global_load_dwordx4 v[22:25], v2, %[base]\n\t"
+             "global_load_dwordx4 v[26:29], v2, %[base] offset:16\n\t"
+             "s_cmp_eq_u64 vcc, 0\n\t"
+             "s_cbranch_scc1 7f\n\t"
+             "s_mov_b64 exec, vcc\n\t"
+             "v_and_b32_e32 v2, 0x3ffffff, %[i]\n\t"
+             "v_mad_u32_u24 v2, v2, 40, %[ldsbase]\n\t"
+             "ds_read_b64 v[22:23], v2\n\t"
+             "ds_read_b64 v[24:25], v2 offset:8\n\t"
+             "ds_read_b64 v[26:27], v2 offset:16\n\t"
+             "ds_read_b64 v[28:29], v2 offset:24\n\t"
+             "ds_read_b32 %[eleft], v2 offset:32\n\t"
+             "7:\n\t"
+             "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+             "s_mov_b64 exec, %[saved]\n\t"
+             "s_bcnt1_i32_b64 %[cntS], %[m]\n\t"
+             "s_add_u32 %[nbox], %[nbox], %[cntS]\n\t"
+             "s_cmp_ge_u32 %[cntS], %[quorum]\n\t"
+             "s_cbranch_scc1 1b\n\t"
+             "2:\n\t"
+             : [e01] "+{v[22:23]}"(w.e01), [e23] "+{v[24:25]}"(w.e23), [e45] "+{v[26:27]}"(w.e45), [sk] "+{v28}"(w.sk), [i] "+v"(w.i), [f0] "+v"(w.f0),
+               [f1] "+v"(w.f1), [f2] "+v"(w.f2), [cnt] "+v"(w.cnt), [m] "=&s"(m), [m2] "=&s"(m2), [m3] "=&s"(m3),
+               [mall] "=&s"(mall), [saved] "=&s"(saved), [cntS] "=&s"(n_inner), [m4] "=&s"(m4), [rho] "+{v29}"(w.rho), [nbox] "+s"(nb),
+               [mlds] "=&s"(mlds), [mhit] "=&s"(mhit), [mpop] "=&s"(mpop), [sp] "+v"(w.sp), [eleft] "+v"(w.eleft)
+             : [p0] "v"(w.p0), [p1] "v"(w.p1), [p2] "v"(w.p2), [p3] "v"(w.p3), [p4] "v"(w.p4), [px] "s"(px), [py] "s"(py),
+               [pz] "s"(pz), [base] "s"(base), [usable] "s"(usable), [quorum] "s"(quorum), [ck] "v"(w.cull_k), [cbase] "v"(w.cull_base),
+               [signs] "v"(signs), [ldsbase] "s"(ldsbase), [stride] "n"(BLOCK * 4)
+             : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "vcc", "scc", "memory");
+    n_box += nb;
+}
+
 // A lane's queue position as the kernels that read the ray again keep it: the top bit carries Walker::usable of the ray
 // as given (queues hold fewer than 2^31 positions)
 constexpr uint32_t IDX_MASK = 0x7FFFFFFFu, IDX_USABLE = 0x80000000u;
@@ -807,19 +1040,25 @@ __device__ __forceinline__ uint32_t lane_now() {
 // the leaf is the one whose assignment of HitInfo.distance survives a rejection — and is finished by tri_finish_step.
 // uv_out: where a winning triangle's barycentrics go instead of the lane's registers (the second half of the ray's hit
 // record; the last triangle to win is the last to write, and no other kind of hit reads them).
-template <bool CULL>
+// ORD: leaves are not met in the reference's order (see "ordered traversal"): equal distances go to the leaf the
+// reference visits first, and a rejected first leaf's distance is only recorded while the ray has no hit.
+template <bool CULL, bool ORD = false>
 __device__ __forceinline__ void closest_update(const Scene& sc, Walker& w, int e, bool ok, bool wrote, float t, float u, float v, float2* uv_out = nullptr) {
     // selects rather than branches around the updates: the record stays in registers
-    const bool better = ok && (!w.c.hit || t < w.c.dist);
+    bool better_ = ok && (!w.c.hit || t < w.c.dist);
+    if constexpr (ORD) { if (ok && w.c.hit && t == w.c.dist) better_ = rank_before(sc, e, w.c.best); }   // a rare tie: settled with two loads
+    const bool better = better_;
     if (CULL && better) cull_update<CULL>(sc, w, t);
-    const bool stale = !ok && wrote && e == w.stale;
+    bool stale_ = !ok && wrote && e == w.stale;
+    if constexpr (ORD) stale_ = stale_ && !w.c.hit;
+    const bool stale = stale_;
     w.c.dist = (better || stale) ? t : w.c.dist;
     w.c.best = better ? e : w.c.best;
     if (uv_out) { if (better) *uv_out = make_float2(u, v); }
     else { w.c.u = better ? u : w.c.u; w.c.v = better ? v : w.c.v; }
     w.c.hit = w.c.hit || better;
 }
-template <bool FOG, bool CULL>
+template <bool FOG, bool CULL, bool ORD = false>
 __device__ __forceinline__ void prim_step(const Scene& sc, const Store& st, Walker& w) {
     const int e = (int)w.f0;
     const f2* E = reinterpret_cast<const f2*>(st.ent) + 4 * (size_t)e;
@@ -829,7 +1068,7 @@ __device__ __forceinline__ void prim_step(const Scene& sc, const Store& st, Walk
     float t = 0;
     bool ok, wrote = false, wait = false;
     if (kind == rt::ENT_TRI) {
-        wait = tri_reach(st.tris, sk_payload(sk), cur, t) && (!w.c.hit || t < w.c.dist || e == w.stale);
+        wait = tri_reach(st.tris, sk_payload(sk), cur, t) && (!w.c.hit || (ORD ? t <= w.c.dist : t < w.c.dist) || e == w.stale);
         ok = false;
     } else {
         const f2 a = E[0], b = E[1], c = E[2];
@@ -839,12 +1078,12 @@ __device__ __forceinline__ void prim_step(const Scene& sc, const Store& st, Walk
     }
     w.reach = wait ? t : 0.0f;
     w.f0 = wait ? w.f0 : w.f1; w.f1 = wait ? w.f1 : w.f2; w.cnt -= wait ? 0u : 1u;
-    closest_update<CULL>(sc, w, e, ok, wrote, t, 0.0f, 0.0f);
+    closest_update<CULL, ORD>(sc, w, e, ok, wrote, t, 0.0f, 0.0f);
 }
 // The second part of Triangle::Intersect for a lane whose head-of-FIFO triangle is waiting for it.
 // LEAN: the alpha mask's place and size are read from the instance record instead of being carried by every lane, and
 // the barycentrics of a winning triangle go straight to the ray's hit record, hit_rec[idx].
-template <bool CULL, bool LEAN = false>
+template <bool CULL, bool LEAN = false, bool ORD = false>
 __device__ __forceinline__ void tri_finish_step(const Scene& sc, const Store& st, Walker& w, float4* hit_rec = nullptr, const uint32_t* idx_slot = nullptr) {
     const int e = (int)w.f0;
     w.f0 = w.f1; w.f1 = w.f2; w.cnt--;
@@ -859,7 +1098,7 @@ __device__ __forceinline__ void tri_finish_step(const Scene& sc, const Store& st
     }
     const bool ok = tri_surface(sc, st.tris, sk_payload(sk), alpha_off, alpha_wh, walker_ray(w), w.reach, t, u, v, wrote);
     w.reach = 0.0f;
-    closest_update<CULL>(sc, w, e, ok, wrote, t, u, v, LEAN ? reinterpret_cast<float2*>(hit_rec + (*idx_slot & IDX_MASK)) + 1 : nullptr);
+    closest_update<CULL, ORD>(sc, w, e, ok, wrote, t, u, v, LEAN ? reinterpret_cast<float2*>(hit_rec + (*idx_slot & IDX_MASK)) + 1 : nullptr);
 }
 // Entries that change the lane's state beyond its position; they wait until every noted leaf has been tested.  Returns
 // true when the ray has finished (closest hit known, plane list merged); the lane is idle from then on.
@@ -873,14 +1112,17 @@ __device__ __forceinline__ void tri_finish_step(const Scene& sc, const Store& st
 // With RELOAD the top bit of outer_tagged says whether the ray as given is admitted to the reciprocal path (IDX_USABLE):
 // that was worked out when the ray was taken up and is not worked out again on the way out (0.25 ms of a 1080p, 64 spp
 // frame; installing the new ray once for the lanes going in and the lanes going out changed nothing).
-template <bool RELOAD = false, bool LEAN = false, bool SAVE = false>
+// ORD > 0: the ordered traversal with stacks of ORD-thread blocks: where the other variants follow a skip link or go
+// on behind an instance's entry, this one pops; what it leaves for later, it pushes.
+template <bool RELOAD = false, bool LEAN = false, bool SAVE = false, int ORD = 0>
 __device__ __forceinline__ bool walker_special(const Scene& sc, const Store& st, Walker& w, float4* outer_a = nullptr, float4* outer_b = nullptr, uint32_t outer_tagged = 0) {
     const uint32_t outer_idx = outer_tagged & IDX_MASK;
     bool done = false;
     const int kind = sk_kind(w.sk);
     if (kind == rt::ENT_END) {
         if (w.inst >= 0) {   // PolygonMesh and its wrappers return to the top level
-            w.i = LEAN ? __float_as_int(st.inst[(size_t)w.inst * rt::RT_INST_F4 + 2].w) : w.resume;
+            if constexpr (ORD != 0) w.i = (int)ord_pop(st, w, ORD * 4);
+            else w.i = LEAN ? __float_as_int(st.inst[(size_t)w.inst * rt::RT_INST_F4 + 2].w) : w.resume;
             w.inst = -1; w.stale = sc.stale_entry;
             if (RELOAD) {
                 const float4 a = SAVE ? outer_a[2 * (size_t)outer_idx] : outer_a[outer_idx], b = SAVE ? outer_a[2 * (size_t)outer_idx + 1] : outer_b[outer_idx];
@@ -909,7 +1151,8 @@ __device__ __forceinline__ bool walker_special(const Scene& sc, const Store& st,
             *reinterpret_cast<float2*>(outer_a + 2 * (size_t)outer_idx + 1) = make_float2(r.d.y, r.d.z);
         }
         walker_set_ray(w, to_instance(i0, i1, i2, walker_ray(w)), sc.fast_div_ok != 0);
-        if (!LEAN) w.resume = w.i + 1;
+        if constexpr (ORD != 0) ord_push(st, w, (uint32_t)st.inst_end[ii], ORD * 4);   // the way back out: the END entry of the instance's range
+        else if (!LEAN) w.resume = w.i + 1;
         w.stale = (w.i == sc.stale_entry) ? __float_as_int(i3.y) : -1;
         w.inst = ii;
         if (!LEAN) { w.alpha_off = __float_as_int(i3.z); w.alpha_wh = __float_as_uint(i3.w); }   // alpha cut-out of the mesh's texture, or -1
@@ -917,15 +1160,24 @@ __device__ __forceinline__ bool walker_special(const Scene& sc, const Store& st,
     } else {
         // an inner entry tested as the reference writes it, with true divisions: a box with min > max on some axis, or
         // a ray that is not admitted to the reciprocal path
-        const int skip = kind == rt::ENT_INNER ? (int)w.sk : __float_as_int(reinterpret_cast<const float*>(st.ent)[8 * (size_t)w.i + 7]);
-        w.i = box_hit(mk(w.e01.x, w.e23.x, w.e45.x), mk(w.e01.y, w.e23.y, w.e45.y), walker_ray(w)) ? w.i + 1 : skip;
+        if constexpr (ORD != 0) {
+            // (no preference between the children here: any order gives the reference's result)
+            const bool hit = box_hit(mk(w.e01.x, w.e23.x, w.e45.x), mk(w.e01.y, w.e23.y, w.e45.y), walker_ray(w));
+            const uint32_t second = kind == rt::ENT_INNER ? w.sk : __float_as_uint(w.rho);
+            const uint32_t first = ((uint32_t)w.i & rt::LINK_LDS) ? w.eleft : (uint32_t)w.i + 1u;
+            if (hit && second != rt::LINK_NONE) ord_push(st, w, second, ORD * 4);
+            w.i = hit ? (int)first : (int)ord_pop(st, w, ORD * 4);
+        } else {
+            const int skip = kind == rt::ENT_INNER ? (int)w.sk : __float_as_int(reinterpret_cast<const float*>(st.ent)[8 * (size_t)w.i + 7]);
+            w.i = box_hit(mk(w.e01.x, w.e23.x, w.e45.x), mk(w.e01.y, w.e23.y, w.e45.y), walker_ray(w)) ? w.i + 1 : skip;
+        }
     }
-    walker_load(st, w);
+    if constexpr (ORD != 0) walker_load_ord(st, w); else walker_load(st, w);
     return done;
 }
 // One round for a wave: the traversal loop; then primitive tests, repeated while at least `prim_quorum` lanes have a
 // noted leaf; then the state-changing entries of lanes that have none left.  Returns true in lanes whose ray finished.
-template <bool LDS, bool FOG, bool RELOAD = false, bool SAVE = false>
+template <bool LDS, bool FOG, bool RELOAD = false, bool SAVE = false, int ORD = 0>
 __device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Walker& w, int quorum, int prim_quorum, int finish_quorum, Prof& prof, uint32_t& n_box,
                                            float4* outer_a = nullptr, float4* outer_b = nullptr, uint32_t outer_idx = 0, float4* hit_rec = nullptr, const uint32_t* idx_slots = nullptr) {
     RT_PROF(unsigned long long t0 = __builtin_readcyclecounter(); prof.rounds++;)
@@ -936,14 +1188,14 @@ __device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Wal
     prim_quorum = max(1, min(prim_quorum, (busy + 1) >> 1));
     finish_quorum = max(1, min(finish_quorum, (busy + 1) >> 1));
     constexpr bool CULL = !LDS && !FOG;   // see "distance culling": large scenes, and never when traversal draws random numbers
-    box_steps<LDS>(st, w, quorum, prof, n_box);
+    if constexpr (ORD != 0) box_steps_ord<ORD>(st, w, quorum, n_box); else box_steps<LDS>(st, w, quorum, prof, n_box);
     RT_PROF(unsigned long long t1 = __builtin_readcyclecounter(); prof.box += t1 - t0;)
     for (;;) {
         const bool has = w.cnt != 0 && w.reach == 0.0f;
         const int n = __popcll(__ballot(has));
         if (n == 0) break;
         RT_PROF(prof.prims++; prof.prim_lanes += n;)
-        if (has) prim_step<FOG, CULL>(sc, st, w);
+        if (has) prim_step<FOG, CULL, ORD != 0>(sc, st, w);
         if (n < prim_quorum) break;
     }
     // triangles waiting for the second part of their test: run it once enough lanes have one (a waiting lane goes on
@@ -953,7 +1205,7 @@ __device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Wal
         const int n = __popcll(__ballot(waiting));
         if (n >= finish_quorum) {
             RT_PROF(prof.finishes++; prof.finish_lanes += n;)
-            if (waiting) tri_finish_step<CULL, RELOAD && LDS>(sc, st, w, hit_rec, idx_slots ? idx_slots + lane_now() : nullptr);
+            if (waiting) tri_finish_step<CULL, RELOAD && LDS, ORD != 0>(sc, st, w, hit_rec, idx_slots ? idx_slots + lane_now() : nullptr);
         }
     }
     RT_PROF(unsigned long long t2 = __builtin_readcyclecounter(); prof.prim += t2 - t1;)
@@ -963,7 +1215,7 @@ __device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Wal
     bool done = false;
     RT_PROF(if (__any(special)) prof.specials++;)
     n_box += (uint32_t)__popcll(__ballot(special && (kind == rt::ENT_INNER_INV || kind == rt::ENT_INNER)));   // boxes tested as written
-    if (special) done = walker_special<RELOAD, RELOAD && LDS, SAVE>(sc, st, w, outer_a, outer_b, idx_slots ? idx_slots[lane_now()] : outer_idx);
+    if (special) done = walker_special<RELOAD, RELOAD && LDS, SAVE, ORD>(sc, st, w, outer_a, outer_b, idx_slots ? idx_slots[lane_now()] : outer_idx);
     RT_PROF(prof.special += __builtin_readcyclecounter() - t2;)
     return done;
 }

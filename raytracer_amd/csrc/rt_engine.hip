@@ -45,6 +45,8 @@ namespace {
 
 constexpr int IBLOCK = 512;         // intersect: 8 waves per block; two blocks per CU, each with its own copy of the scene in LDS
 constexpr long long WIDE_MIN_PATHS = 1ll << 24;   // batches of at least this many paths run their large passes with 768-thread blocks
+constexpr int OBLOCK = 1024;        // intersect, ordered traversal: one block per CU, its stacks and the tree's upper levels share the CU's LDS
+constexpr int MAX_ORD_BYTES = 160 * 1024 - 256;
 constexpr int MAX_STAGED_BYTES = 80 * 1024;   // largest scene copy a block keeps in LDS (two blocks share a CU's 160 KiB)
 // Reservation counters of the intersect passes: the queue of a pass is cut into NCUR ranges with a counter each (a single
 // counter would take every reservation of the grid, and additions to one address are served one after another); the
@@ -207,9 +209,24 @@ __device__ __forceinline__ bool fetch_ray(const Cam& cam, const Cfg& g, const Ba
 
 // Where the traversal reads the scene from: the block's own copy in LDS (entries, triangles, instance and plane records,
 // copied once; blocks are persistent), or global memory when the scene is too large for that.
-template <bool STAGED>
-__device__ __forceinline__ Store stage_scene(const Scene& sc, float4* smem) {
+// ORD_BLOCK > 0 (the ordered traversal, blocks of ORD_BLOCK threads): the block's LDS holds the threads' stacks (slot s
+// of thread t at dword s * ORD_BLOCK + t) and behind them the table of the tree's upper levels, copied here once.
+template <bool STAGED, int ORD_BLOCK = 0>
+__device__ __forceinline__ Store stage_scene(const Scene& sc, float4* smem, const OrdScene* os = nullptr) {
     Store st;
+    st.lds0 = nullptr; st.lds0_addr = 0; st.top_addr = 0; st.stack_addr = 0; st.root_link = 0; st.inst_end = nullptr;
+    if (ORD_BLOCK) {
+        uint32_t* l = reinterpret_cast<uint32_t*>(smem);
+        const int stack_dwords = os->stack_slots * ORD_BLOCK, tab_dwords = os->n_top_tab * rt::TOP_REC_DWORDS;
+        for (int k = threadIdx.x; k < tab_dwords; k += ORD_BLOCK) l[stack_dwords + k] = os->top_tab[k];
+        l[threadIdx.x] = (uint32_t)sc.top_end;   // slot 0: where the walk ends
+        __syncthreads();
+        st.ent = os->ent_ord; st.tris = sc.tris; st.inst = sc.inst; st.planes = sc.planes;
+        st.root_link = os->root_link; st.inst_end = os->inst_end;
+        st.lds0 = l; st.lds0_addr = (uint32_t)(uintptr_t)l;     // LDS addresses are 32-bit offsets
+        st.stack_addr = st.lds0_addr; st.top_addr = st.lds0_addr + 4u * (uint32_t)stack_dwords;
+        return st;
+    }
     if (STAGED) {
         const int n_ent4 = 2 * sc.n_entries, n_tri4 = rt::RT_TRI_F4 * sc.n_tris, n_inst4 = rt::RT_INST_F4 * sc.n_inst;
         for (int k = threadIdx.x; k < n_ent4; k += blockDim.x) smem[k] = sc.ent[k];
@@ -231,7 +248,7 @@ __device__ __forceinline__ uint32_t range_size(uint32_t n_stripes, uint32_t r) {
 // generation of camera rays reads); held in scalar registers for the whole kernel they push other values out into lanes
 // of a vector register, and every use of those costs a vector instruction.  The pointer is passed through an empty asm
 // statement so that the loads stay where they are written instead of being hoisted out of the loop.
-struct IntersectArgs { Scene sc; Cam cam; Cfg g; Batch bt; Queues q; int pass; Debug dbg; Tune tune; };   // the kernel's parameter list
+struct IntersectArgs { Scene sc; Cam cam; Cfg g; Batch bt; Queues q; int pass; Debug dbg; Tune tune; OrdScene os; };   // the kernel's parameter list
 template <typename T>
 __device__ __forceinline__ T kernarg_read(size_t offset) {
     typedef const __attribute__((address_space(4))) uint32_t* KP;
@@ -250,14 +267,15 @@ __device__ __forceinline__ uint32_t* lane_slots() { __shared__ uint32_t slots[N]
 
 // ---- intersect (World.cpp:105-119) ----------------------------------------------------------------------------------
 // (the parameter list is mirrored by IntersectArgs, through which kernarg_read finds cam, g and bt: change both together)
-template <bool FIRST, bool STAGED, bool FOG, int BLOCK = IBLOCK, int MIN_WAVES = 1>
-__global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, Cam cam, Cfg g, Batch bt, Queues q, int pass, Debug dbg, Tune tune) {
+template <bool FIRST, bool STAGED, bool FOG, int BLOCK = IBLOCK, int MIN_WAVES = 1, bool ORD = false>
+__global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, Cam cam, Cfg g, Batch bt, Queues q, int pass, Debug dbg, Tune tune, OrdScene os) {
+    static_assert(!ORD || (!STAGED && !FOG), "the ordered traversal is for scenes read from memory, without fog");
     extern __shared__ float4 smem[];
     const uint32_t n_in = FIRST ? (uint32_t)bt.n_pixels * (uint32_t)(g.S * g.S) : q.counts[pass];
     // a pass with few rays: blocks beyond one smallest reservation per wave leave before they copy the scene
     const uint32_t blocks_used = min((uint32_t)gridDim.x, n_in / ((uint32_t)tune.min_chunk * (BLOCK / 64)) + 1u);
     if (n_in == 0u || blockIdx.x >= blocks_used || cancelled(bt)) return;
-    const Store st = stage_scene<STAGED>(sc, smem);
+    const Store st = stage_scene<STAGED, ORD ? BLOCK : 0>(sc, smem, &os);
     const int qin = (pass + 1) & 1;
     // Range r of the queue is every NCUR-th stripe of STRIPE positions, starting with stripe r: all ranges move through
     // the queue side by side, so the grid still works on one neighbourhood of the image at a time.  A wave starts on the
@@ -338,7 +356,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, C
                     if (walker_is_idle(w) && o < mine_end && idx < n_in) {
                         Ray ray; Rng rng; uint32_t slot, depth;
                         if (fetch_ray<true>(cam_now, g_now, bt_now, q, qin, dbg, idx, ray, rng, slot, depth, FOG)) {
-                            walker_start<CULL>(sc, st, w, ray, rng);
+                            if constexpr (ORD) walker_start_ord<CULL, BLOCK>(sc, st, w, ray, rng); else walker_start<CULL>(sc, st, w, ray, rng);
                             const uint32_t tagged = RELOAD && w.usable ? idx | IDX_USABLE : idx;
                             if constexpr (LEAN) my_slot[lane_now()] = tagged; else my_idx = tagged;
                         }
@@ -346,7 +364,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, C
                 } else if (walker_is_idle(w) && o < mine_end && idx < n_in) {
                     Ray ray; Rng rng; uint32_t slot, depth;
                     if (fetch_ray<false>(cam, g, bt, q, qin, dbg, idx, ray, rng, slot, depth, FOG)) {
-                        walker_start<CULL>(sc, st, w, ray, rng);
+                        if constexpr (ORD) walker_start_ord<CULL, BLOCK>(sc, st, w, ray, rng); else walker_start<CULL>(sc, st, w, ray, rng);
                         const uint32_t tagged = RELOAD && w.usable ? idx | IDX_USABLE : idx;
                         if constexpr (LEAN) my_slot[lane_now()] = tagged; else my_idx = tagged;
                     }
@@ -371,7 +389,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, C
         // per SIMD was measured on both kinds of scene and gained nothing: 256-thread blocks on the 100 000-primitive
         // scene 92.9 against 92.3 ms; 640-thread blocks with the scene in LDS lose a fifth, their ten waves do not spread
         // evenly over four SIMDs.)
-        if (walk_round<STAGED, FOG, RELOAD, FIRST>(sc, st, w, tune.quorum, tune.prim_quorum, tune.finish_quorum, prof, n_box, q.a[qin], q.b[qin], my_idx, q.hit, my_slot)) {
+        if (walk_round<STAGED, FOG, RELOAD, FIRST, ORD ? BLOCK : 0>(sc, st, w, tune.quorum, tune.prim_quorum, tune.finish_quorum, prof, n_box, q.a[qin], q.b[qin], my_idx, q.hit, my_slot)) {
             // (the lean walker has written the barycentrics of its winning triangle already)
             if constexpr (LEAN) *reinterpret_cast<float2*>(q.hit + (my_slot[lane_now()] & IDX_MASK)) = make_float2(w.c.dist, __int_as_float(w.c.best));
             else q.hit[my_idx & IDX_MASK] = make_float4(w.c.dist, __int_as_float(w.c.best), w.c.u, w.c.v);
@@ -694,10 +712,12 @@ struct rt_engine {
     bool frame_dirty = true;            // the frame buffer differs from h_frame (true from the start: h_frame is allocated uninitialised,
                                         // and the first complete map must copy the zeroed frame buffer, FrameManager.cpp:13)
     Scene sc{};
+    OrdScene os{};
     bool have_scene = false, have_camera = false;
     Cam cam{};
     std::vector<void*> scene_allocs;
     size_t staged_bytes = 0;            // LDS the intersect kernel needs to hold the scene; 0 = read it from global memory
+    size_t ord_bytes = 0;               // LDS of the ordered traversal (stacks + table of the upper levels); 0 = the scene is not walked that way
     Queues q{};
     int n_counts = 0;
     uint8_t* d_frame = nullptr;
@@ -788,7 +808,7 @@ void launch_intersect(rt_engine* e, hipStream_t st, const Cfg& g, const Batch& b
     Tune tune = e->tune;
     if (!e->staged_bytes) tune.quorum = e->quorum_mem;
 #define RT_LAUNCH_INTERSECT(STAGED, FOG, LDS_BYTES) \
-    hipLaunchKernelGGL((intersect_kernel<FIRST, STAGED, FOG>), dim3(blocks), dim3(IBLOCK), LDS_BYTES, st, e->sc, e->cam, g, bt, q, pass, e->dbg, tune)
+    hipLaunchKernelGGL((intersect_kernel<FIRST, STAGED, FOG>), dim3(blocks), dim3(IBLOCK), LDS_BYTES, st, e->sc, e->cam, g, bt, q, pass, e->dbg, tune, e->os)
     // Large passes over a scene in LDS: 768-thread blocks, twelve waves that spread evenly over the four SIMDs, two blocks
     // per CU as before: six waves per SIMD instead of four, for which the kernel stays within 80 registers (RELOAD, LEAN,
     // SAVE in rt_device.h; the variant keeps one dword per thread in LDS beside the scene).  Measured on the 1920 x 1080
@@ -798,7 +818,13 @@ void launch_intersect(rt_engine* e, hipStream_t st, const Cfg& g, const Batch& b
     const bool wide = e->wide_blocks < 0 ? (long long)bt.n_pixels * (g.S * g.S) >= WIDE_MIN_PATHS : e->wide_blocks != 0;
     if (e->staged_bytes && e->staged_bytes + 768 * sizeof(uint32_t) <= (size_t)MAX_STAGED_BYTES && !fog && wide && pass <= e->wide_max_pass && (!FIRST || e->wide_first)) {
         if (FIRST) tune.refill_at = e->refill_at_wide;
-        hipLaunchKernelGGL((intersect_kernel<FIRST, true, false, 768, 6>), dim3(blocks), dim3(768), e->staged_bytes, st, e->sc, e->cam, g, bt, q, pass, e->dbg, tune);
+        hipLaunchKernelGGL((intersect_kernel<FIRST, true, false, 768, 6>), dim3(blocks), dim3(768), e->staged_bytes, st, e->sc, e->cam, g, bt, q, pass, e->dbg, tune, e->os);
+        return;
+    }
+    if (e->ord_bytes && !e->staged_bytes && !fog) {
+        // a scene read from memory: near child first, the far one on a stack in LDS, the tree's upper levels in LDS too
+        // (rt_device.h, "ordered traversal"); one 1024-thread block per CU owns the CU's LDS
+        hipLaunchKernelGGL((intersect_kernel<FIRST, false, false, OBLOCK, 1, true>), dim3(e->n_cus), dim3(OBLOCK), e->ord_bytes, st, e->sc, e->cam, g, bt, q, pass, e->dbg, tune, e->os);
         return;
     }
     if (e->staged_bytes) { if (fog) RT_LAUNCH_INTERSECT(true, true, e->staged_bytes); else RT_LAUNCH_INTERSECT(true, false, e->staged_bytes); }
@@ -934,6 +960,8 @@ int init_engine(rt_engine* e, const rt_config* cfg) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<false, true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<false, true, false, 768, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<true, true, false, 768, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<true, false, false, OBLOCK, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_ORD_BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<false, false, false, OBLOCK, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_ORD_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
 #ifdef RT_PROFILE
@@ -1101,10 +1129,66 @@ static int rt_engine_set_scene_impl(rt_engine* e, const rt_scene* s) {
     sc.has_fog = has_fog ? 1 : 0;
     sc.cull_delta = f->cull_delta; sc.cull_cabs = f->cull_cabs; sc.cull_2rmax = f->cull_2rmax;
     sc.cull_on = (e->cfg.flags & RT_FLAG_NO_CULL) ? 0 : 1;
-    e->sc = sc;
     // stage the whole scene in LDS when two 512-thread blocks per CU can each hold it (160 KiB per CU)
     const size_t need = (inter.size() + f->tris.size() + f->inst.size() + f->planes.size()) * 16;
     e->staged_bytes = (need <= (size_t)MAX_STAGED_BYTES && !(e->cfg.flags & RT_FLAG_NO_LDS)) ? need : 0;
+    // Otherwise, without fog: the ordered traversal, if a ray's stack fits (layout of its entries and table: rt_flat.h)
+    e->ord_bytes = 0;
+    e->os = OrdScene{};
+    const size_t stack_bytes = (size_t)f->stack_need * OBLOCK * 4;
+    if (!e->staged_bytes && !has_fog && !(e->cfg.flags & RT_FLAG_NO_ORDER) && f->ent_lo.size() < rt::LINK_LDS && stack_bytes + 4096 <= (size_t)MAX_ORD_BYTES) {
+        const size_t n = f->ent_lo.size();
+        auto is_plain_inner = [&](size_t i) { return rt::bits_i(f->ent_hi[i].w) == rt::ENT_INNER && rt::bits_i(inter[2 * i + 1].z) >> rt::SK_SHIFT == rt::ENT_INNER; };
+        // the upper levels of the top-level tree, level by level, as many whole levels as fit beside the stacks
+        std::vector<int32_t> table, level;               // entry indices: in the table, in the level being tried
+        if (is_plain_inner(0)) level.push_back(0);
+        const size_t max_records = std::min<size_t>(((size_t)MAX_ORD_BYTES - stack_bytes) / (rt::TOP_REC_DWORDS * 4), (size_t)rt::LINK_INDEX);
+        while (!level.empty() && table.size() + level.size() <= max_records) {
+            table.insert(table.end(), level.begin(), level.end());
+            std::vector<int32_t> next;
+            for (int32_t i : level)
+                for (int32_t c : {i + 1, f->ent_right[i]})
+                    if (c >= 0 && is_plain_inner((size_t)c)) next.push_back(c);
+            level.swap(next);
+        }
+        std::vector<int32_t> record_of(n, -1);
+        for (size_t k = 0; k < table.size(); k++) record_of[table[k]] = (int32_t)k;
+        auto link_of = [&](int32_t entry) { return entry < 0 ? rt::LINK_NONE : record_of[entry] >= 0 ? (rt::LINK_LDS | (uint32_t)record_of[entry]) : (uint32_t)entry; };
+        // rho rounded up to a multiple of four units in the last place, the axis in the two bits that frees: never below
+        // the bound's own value; +inf ("never cull") becomes a NaN, which no comparison finds smaller than anything
+        auto rho_axis = [&](size_t i) {
+            uint32_t b = (uint32_t)rt::bits_i(inter[2 * i + 1].w);
+            if (b < 0x7F800000u) b = (b + 3u) & ~3u;
+            return (b & ~3u) | (uint32_t)f->ent_axis[i];
+        };
+        std::vector<rt::F4> ord(inter);
+        for (size_t i = 0; i < n; i++) {
+            if (rt::bits_i(f->ent_hi[i].w) != rt::ENT_INNER) continue;
+            const uint32_t second = link_of(f->ent_right[i]);
+            if (is_plain_inner(i)) { ord[2 * i + 1].z = rt::bits_f((int32_t)second); ord[2 * i + 1].w = rt::bits_f((int32_t)rho_axis(i)); }
+            else ord[2 * i + 1].w = rt::bits_f((int32_t)second);          // INNER_INV: kind in dword 6, the link in dword 7
+        }
+        std::vector<uint32_t> tab(table.size() * rt::TOP_REC_DWORDS, 0u);
+        for (size_t k = 0; k < table.size(); k++) {
+            const size_t i = (size_t)table[k];
+            uint32_t* r = &tab[k * rt::TOP_REC_DWORDS];
+            memcpy(r, &ord[2 * i], 32);
+            r[8] = link_of((int32_t)i + 1);
+        }
+        std::vector<int32_t> inst_end(std::max<size_t>(1, f->inst.size() / rt::RT_INST_F4), 0);
+        for (size_t k = 0; k + rt::RT_INST_F4 <= f->inst.size(); k += rt::RT_INST_F4) inst_end[k / rt::RT_INST_F4] = rt::bits_i(f->inst[k + 2].w);
+        float4* d_ord; uint32_t* d_tab; int32_t* d_end;
+        if (int rc = upload(&d_ord, ord.data(), ord.size() * 16)) return rc;
+        e->scene_allocs.push_back(d_ord);
+        if (int rc = upload(&d_tab, tab.data(), tab.size() * 4)) return rc;
+        e->scene_allocs.push_back(d_tab);
+        if (int rc = upload(&d_end, inst_end.data(), inst_end.size() * 4)) return rc;
+        e->scene_allocs.push_back(d_end);
+        e->os.ent_ord = d_ord; e->os.top_tab = d_tab; e->os.inst_end = d_end;
+        e->os.n_top_tab = (int)table.size(); e->os.stack_slots = f->stack_need; e->os.root_link = link_of(0);
+        e->ord_bytes = stack_bytes + tab.size() * 4;
+    }
+    e->sc = sc;
     e->have_scene = true;
     return RT_OK;
 }

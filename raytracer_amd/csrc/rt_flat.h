@@ -30,6 +30,18 @@
 //   INSTANCE   0 0 0 0 0 0 | kind, instance index | 0
 //   END, IDLE  0 ... | kind | 0
 //
+// Ordered entries — a second copy of the device entries for scenes that are read from memory (rt_device.h, "ordered
+// traversal"): the same indices and the same leaf entries; an inner entry names its SECOND child instead of the entry
+// to skip to (its first child is still the next entry), because the traversal keeps the child it visits later on a
+// per-ray stack and therefore can take the two in either order:
+//   INNER      six bounds | link of the second child (LINK_NONE when the node lists one child) | rho, its low two
+//              mantissa bits replaced by the axis along which the first child's box begins no later than the second's
+//              (3 for a single child; rho is rounded up first, +inf becomes a NaN: both keep "never cull less")
+//   INNER_INV  six bounds | kind | link of the second child
+// A link is an entry index, or LINK_LDS | k for the k-th record of the table of the tree's upper levels that every
+// block copies into LDS: ten dwords each — six bounds | link of the second child | rho and axis as above | link of the
+// first child | 0.
+//
 // Triangle (RT_TRI_F4 = 6 records):  (v0.xyz, -) (v1.xyz, -) (v2.xyz, -) (uv0.xy, uv1.xy) (uv2.xy, n.x, n.y) (n.z, -, -, -)
 //   on the device:                    (v0.xyz, v1.x) (v1 - v0, v1.y) (v2 - v0, v1.z) (uv0.xy, uv1.xy) (uv2.xy, n.x, n.y) (n.z, v2.xyz)
 // Instance (RT_INST_F4 = 4):         (offset.xyz, has_move) (pivot.xyz, rot axis or -1) (sin, cos, begin, end)
@@ -50,6 +62,9 @@ enum : int { ENT_INNER = 0, ENT_SPHERE = 1, ENT_CUBE = 2, ENT_TRI = 3, ENT_FOG =
 constexpr int RT_TRI_F4 = 6, RT_INST_F4 = 4, RT_OBJ_F4 = 4;
 constexpr int SK_SHIFT = 28;
 constexpr uint32_t SK_MASK = (1u << SK_SHIFT) - 1u;
+
+constexpr uint32_t LINK_LDS = 1u << 26, LINK_INDEX = LINK_LDS - 1u, LINK_NONE = LINK_INDEX;
+constexpr int TOP_REC_DWORDS = 10;
 
 inline float bits_f(int32_t i) { union { int32_t i; float f; } u; u.i = i; return u.f; }
 inline int32_t bits_i(float f) { union { int32_t i; float f; } u; u.f = f; return u.i; }

@@ -75,6 +75,12 @@ struct rt_scene_flat {
     // scene-wide constants of the bound.
     std::vector<float> ent_rho;
     float cull_delta = 0, cull_cabs = 0, cull_2rmax = 0;
+    // Ordered traversal: per inner entry the index of its second child's entry (the first child is the next entry; -1
+    // when the node lists a single child) and the axis along which the first child's box starts no later than the
+    // second's (3 for a single child); and the stack slots a ray can need at most.
+    std::vector<int32_t> ent_right;
+    std::vector<uint8_t> ent_axis;
+    int32_t stack_need = 0;
 };
 
 const rt_scene_flat* rt_scene_get_flat(const struct rt_scene* s);

@@ -143,6 +143,7 @@ struct TreeBuild {
         node.kind = NODE;
         node.left = left;
         node.right = right;
+        node.axis = axis;      // the children were ordered by their boxes' minimum along this axis: `left` has the smaller one
         // GetSurroundingBox (Object.cpp:156-166): fmin / fmax per component
         node.box.mn = {std::fmin(bl.mn.x, br.mn.x), std::fmin(bl.mn.y, br.mn.y), std::fmin(bl.mn.z, br.mn.z)};
         node.box.mx = {std::fmax(bl.mx.x, br.mx.x), std::fmax(bl.mx.y, br.mx.y), std::fmax(bl.mx.z, br.mx.z)};
@@ -285,8 +286,13 @@ struct Flattener {
         emit(o.left, top_level);
         // a node over a single object has it as both children (Object.cpp:198-200) and tests it twice; for a fog volume
         // the second test draws a new random number and can hit where the first did not, so it is listed twice
-        if (o.right != o.left || draws_random(o.left)) emit(o.right, top_level);
+        int right_at = -1;
+        if (o.right != o.left || draws_random(o.left)) { right_at = (int)f.ent_lo.size(); emit(o.right, top_level); }
         f.ent_lo[at].w = bits_f((int)f.ent_lo.size());
+        f.ent_right.resize(f.ent_lo.size(), -1);
+        f.ent_axis.resize(f.ent_lo.size(), 3);
+        f.ent_right[at] = right_at;
+        f.ent_axis[at] = (uint8_t)(right_at >= 0 ? (o.axis >= 0 && o.axis <= 2 ? o.axis : 0) : 3);
     }
     bool draws_random(int idx) const {
         while (s.objs[idx].kind == MOVE || s.objs[idx].kind == ROT) idx = s.objs[idx].target;
@@ -331,6 +337,26 @@ void flatten(rt_scene& s) {
     f.idle_entry = (int)f.ent_lo.size();
     f.ent_lo.push_back({0, 0, 0, 0});
     f.ent_hi.push_back({0, 0, 0, bits_f(ENT_IDLE)});
+    f.ent_right.resize(f.ent_lo.size(), -1);
+    f.ent_axis.resize(f.ent_lo.size(), 3);
+    // Ordered traversal (rt_device.h, "ordered traversal") keeps the children it has yet to visit on a per-ray stack: an
+    // inner entry with two children adds one while its first child's subtree is walked, a mesh instance one (the way
+    // back out) while its own tree is walked; one more slot holds the end of the top-level list.  Children follow their
+    // parents in the entry array and the instances' ranges follow the top-level list, so one pass downwards suffices.
+    {
+        std::vector<int> need(f.ent_lo.size(), 0);
+        for (int i = (int)f.ent_lo.size() - 1; i >= 0; i--) {
+            const int kind = bits_i(f.ent_hi[i].w);
+            if (kind == ENT_INNER) {
+                const int l = need[(size_t)i + 1], r = f.ent_right[i] >= 0 ? need[f.ent_right[i]] : -1;
+                need[i] = r < 0 ? l : 1 + std::max(l, r);
+            } else if (kind == ENT_INSTANCE) {
+                const size_t k = (size_t)bits_i(f.ent_lo[i].x) * RT_INST_F4;
+                if (k + RT_INST_F4 <= f.inst.size()) need[i] = 1 + need[bits_i(f.inst[k + 2].z)];
+            }
+        }
+        f.stack_need = 1 + need[0];
+    }
     f.fast_div_ok = true;
     for (size_t i = 0; i < f.ent_lo.size(); i++) {
         if (bits_i(f.ent_hi[i].w) != ENT_INNER) continue;

@@ -18,6 +18,7 @@ TEX_COLOR, TEX_CHECKER, TEX_IMAGE = 0, 1, 2
 TRACE_STATIC_MAX_RAYS = 32768   # RT_TRACE_STATIC_MAX_RAYS
 FLAG_NO_CULL = 1                # RT_FLAG_NO_CULL
 FLAG_NO_LDS = 2                 # RT_FLAG_NO_LDS
+FLAG_NO_ORDER = 4               # RT_FLAG_NO_ORDER
 
 f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")

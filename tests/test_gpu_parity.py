@@ -690,7 +690,10 @@ def test_random_scenes_bit_exact(rt, orc, assets, seed, monkeypatch):
     # instances, rotations and fog in them), with and without distance culling
     # ... and from on-chip memory with the 768-thread blocks that large batches use for their first bounce passes
     monkeypatch.setenv("RT_WIDE_BLOCKS", "1")
-    for flags in (rt.engine.FLAG_NO_LDS, rt.engine.FLAG_NO_LDS | rt.engine.FLAG_NO_CULL, 0):
+    # (scenes without fog read from memory are walked near side first with a stack; FLAG_NO_ORDER selects the
+    # reference's order without one, as scenes with fog are always walked)
+    E = rt.engine
+    for flags in (E.FLAG_NO_LDS, E.FLAG_NO_LDS | E.FLAG_NO_CULL, E.FLAG_NO_LDS | E.FLAG_NO_ORDER, E.FLAG_NO_LDS | E.FLAG_NO_ORDER | E.FLAG_NO_CULL, 0):
         m = make_engine(rt, scene, W, H, S, B, cam, flags=flags)
         m.keep_samples(True)
         frame_m = m.render_frame(seed)
@@ -798,13 +801,22 @@ def test_distance_culling_changes_nothing(rt, orc, assets):
     col = e.ray_color(o, d, 4, keys)
     assert_bits(col, e0.ray_color(o, d, 4, keys), "radiance with and without culling")
     assert_bits(col, osc.ray_color(o, d, 4, keys), "radiance vs the oracle")
-    # and it does skip work: a frame's executed slab tests drop well below what the reference algorithm performs
+    # the same rays through the kernels that take a node's children in the reference's order (no stack); e and e0 above
+    # visit the near child first
+    e1 = make_engine(rt, scene, 256, 256, 2, 4, cam, flags=rt.engine.FLAG_NO_ORDER)
+    assert_bits(e1.ray_color(o, d, 4, keys), col, "radiance in the reference's child order")
+    # and it does skip work: a frame's executed slab tests drop well below what the reference algorithm performs, and
+    # further when the near child is visited first
     a = e.render_frame(5)
     n_cull = e.stats()["box_tests"]
     a0 = e0.render_frame(5)
     n_all = e0.stats()["box_tests"]
+    a1 = e1.render_frame(5)
+    n_unordered = e1.stats()["box_tests"]
     assert_bits(a, a0, "frame with and without culling")
-    assert 0 < n_cull < 0.7 * n_all, (n_cull, n_all)
+    assert_bits(a, a1, "frame near side first and in the reference's order")
+    assert 0 < n_cull < n_unordered < 0.7 * n_all, (n_cull, n_unordered, n_all)
+    print(f"slab tests per frame: {n_all} all, {n_unordered} culled in the reference's order, {n_cull} culled near side first")
 
 
 @pytest.fixture(scope="module")
