@@ -574,7 +574,8 @@ __device__ __forceinline__ void walker_start(const Scene& sc, const Store& st, W
 // consumed by then and the fetch at the end of the iteration overwrites for every lane that stepped.
 // Every lane of the wave must be enabled at the call.
 // RT_PROFILE builds (make PROF=1) time the phases of every round with the shader clock; see intersect_kernel
-struct Prof { unsigned long long box = 0, prim = 0, special = 0, refill = 0; unsigned rounds = 0, prims = 0, prim_lanes = 0, specials = 0, box_iters = 0, box_lanes = 0, finishes = 0, finish_lanes = 0; };
+struct Prof { unsigned long long box = 0, prim = 0, special = 0, refill = 0; unsigned rounds = 0, prims = 0, prim_lanes = 0, specials = 0, box_iters = 0, box_lanes = 0, finishes = 0, finish_lanes = 0;
+              unsigned sp_exec[4] = {0, 0, 0, 0}, sp_lanes[4] = {0, 0, 0, 0}; };   // state-changing entries by kind: end of walk, end of instance, instance, box tested as written
 #ifdef RT_PROFILE
 #define RT_PROF(x) x
 #else
@@ -1214,6 +1215,20 @@ __device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Wal
                                         (kind == rt::ENT_INNER && !w.usable));
     bool done = false;
     RT_PROF(if (__any(special)) prof.specials++;)
+#ifdef RT_PROFILE
+    {
+        const bool k0 = special && kind == rt::ENT_END && w.inst < 0;
+        const bool k1 = special && kind == rt::ENT_END && w.inst >= 0;
+        const bool k2 = special && kind == rt::ENT_INSTANCE;
+        const bool k3 = special && !k0 && !k1 && !k2;
+        const int n0 = __popcll(__ballot(k0));
+        const int n1 = __popcll(__ballot(k1));
+        const int n2 = __popcll(__ballot(k2));
+        const int n3 = __popcll(__ballot(k3));
+        prof.sp_exec[0] += n0 != 0; prof.sp_exec[1] += n1 != 0; prof.sp_exec[2] += n2 != 0; prof.sp_exec[3] += n3 != 0;
+        prof.sp_lanes[0] += n0; prof.sp_lanes[1] += n1; prof.sp_lanes[2] += n2; prof.sp_lanes[3] += n3;
+    }
+#endif
     n_box += (uint32_t)__popcll(__ballot(special && (kind == rt::ENT_INNER_INV || kind == rt::ENT_INNER)));   // boxes tested as written
     if (special) done = walker_special<RELOAD, RELOAD && LDS, SAVE, ORD>(sc, st, w, outer_a, outer_b, idx_slots ? idx_slots[lane_now()] : outer_idx);
     RT_PROF(prof.special += __builtin_readcyclecounter() - t2;)

@@ -399,13 +399,14 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, C
     if (lane_now() == 0 && n_box) atomicAdd(reinterpret_cast<unsigned long long*>(q.counts + BOX_COUNT_AT) + pass, (unsigned long long)n_box);
 #ifdef RT_PROFILE
     if (dbg.prof && lane_now() == 0 && prof.rounds) {   // per pass: 12 counters summed over the waves that had work
-        unsigned long long* p = dbg.prof + 16 * (pass < 15 ? pass : 15);
+        unsigned long long* p = dbg.prof + 32 * (pass < 15 ? pass : 15);
         atomicAdd(p + 0, 1ull); atomicAdd(p + 1, __builtin_readcyclecounter() - t_start); atomicAdd(p + 2, (unsigned long long)prof.rounds);
         atomicAdd(p + 3, prof.box); atomicAdd(p + 4, prof.prim); atomicAdd(p + 5, prof.special); atomicAdd(p + 6, prof.refill);
         atomicAdd(p + 7, (unsigned long long)prof.prims); atomicAdd(p + 8, (unsigned long long)prof.prim_lanes);
         atomicAdd(p + 9, (unsigned long long)prof.specials); atomicAdd(p + 10, (unsigned long long)n_refills);
         atomicAdd(p + 11, (unsigned long long)prof.box_iters); atomicAdd(p + 12, (unsigned long long)prof.box_lanes);
         atomicAdd(p + 13, (unsigned long long)prof.finishes); atomicAdd(p + 14, (unsigned long long)prof.finish_lanes);
+        for (int k = 0; k < 4; k++) { atomicAdd(p + 16 + k, (unsigned long long)prof.sp_exec[k]); atomicAdd(p + 20 + k, (unsigned long long)prof.sp_lanes[k]); }
     }
 #endif
 }
@@ -965,8 +966,8 @@ int init_engine(rt_engine* e, const rt_config* cfg) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
 #ifdef RT_PROFILE
-    HIP_TRY(hipMalloc((void**)&e->dbg.prof, sizeof(unsigned long long) * 16 * 16));
-    HIP_TRY(hipMemset(e->dbg.prof, 0, sizeof(unsigned long long) * 16 * 16));
+    HIP_TRY(hipMalloc((void**)&e->dbg.prof, sizeof(unsigned long long) * 32 * 16));
+    HIP_TRY(hipMemset(e->dbg.prof, 0, sizeof(unsigned long long) * 32 * 16));
 #endif
     if (const char* v = getenv("RT_REFILL_AT")) e->tune.refill_at = e->refill_at_wide = std::max(1, std::min(64, atoi(v)));
     if (const char* v = getenv("RT_REFILL_AT_BOUNCE")) e->tune.refill_at_bounce = std::max(1, std::min(64, atoi(v)));
@@ -1543,17 +1544,19 @@ static int rt_engine_get_stats_impl(rt_engine* e, rt_stats* out) {
     }
 #ifdef RT_PROFILE
     if (e->dbg.prof) {
-        unsigned long long h[16 * 16];
+        unsigned long long h[32 * 16];
         HIP_TRY(hipMemcpy(h, e->dbg.prof, sizeof h, hipMemcpyDeviceToHost));
         HIP_TRY(hipMemset(e->dbg.prof, 0, sizeof h));
         fprintf(stderr, "pass waves cycles/wave rounds/wave box%% prim%% special%% refill%% prim_steps/wave lanes/prim_step specials/wave refills/wave (all renders since the last call)\n");
         for (int k = 0; k < 16; k++) {
-            const unsigned long long* p = h + 16 * k;
+            const unsigned long long* p = h + 32 * k;
             if (!p[0]) continue;
             const double w = (double)p[0], cyc = (double)p[1];
             const double iters = (double)p[11], lanes = (double)p[12];
             fprintf(stderr, "%2d %6llu %9.0f %7.1f %5.1f %5.1f %5.1f %5.1f %7.1f %5.1f %6.1f %6.1f  box iters/wave %.0f lanes/iter %.1f  tri finishes/wave %.1f lanes %.1f\n", k, p[0], cyc / w, p[2] / w, 100.0 * p[3] / cyc,
                     100.0 * p[4] / cyc, 100.0 * p[5] / cyc, 100.0 * p[6] / cyc, p[7] / w, p[7] ? (double)p[8] / p[7] : 0.0, p[9] / w, p[10] / w, iters / w, iters ? lanes / iters : 0.0, p[13] / w, p[13] ? (double)p[14] / p[13] : 0.0);
+            fprintf(stderr, "     state changes per wave (lanes each): end of walk %.1f (%.1f), end of instance %.1f (%.1f), instance %.1f (%.1f), box as written %.1f (%.1f)\n",
+                    p[16] / w, p[16] ? (double)p[20] / p[16] : 0.0, p[17] / w, p[17] ? (double)p[21] / p[17] : 0.0, p[18] / w, p[18] ? (double)p[22] / p[18] : 0.0, p[19] / w, p[19] ? (double)p[23] / p[19] : 0.0);
         }
     }
 #endif
