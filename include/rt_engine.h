@@ -65,6 +65,11 @@ typedef struct rt_config {
  * on-chip memory; this flag makes the kernel take the children in the reference's order, without a stack — the same
  * results through the other variant of the kernel, for comparisons and tests. */
 #define RT_FLAG_NO_ORDER 4
+/* Which leaves BVH_Node::Intersect tests is decided by the boxes of the trees' lowest nodes alone (every box above is a
+ * union of boxes below it and the slab test is monotone in the box), so the engine walks a hierarchy of its own above
+ * those nodes — fewer box tests, the same leaves, the same results.  This flag makes it walk the reference's hierarchy
+ * (Object.cpp:181-225) throughout — for comparisons and tests. */
+#define RT_FLAG_NO_REGROUP 8
 void rt_config_defaults(rt_config* cfg);   /* the values of Constants.h:4-17 */
 
 /* ---------------------------------------------------------------------------------------------------------
@@ -120,6 +125,14 @@ int rt_scene_dump_objects(const rt_scene* s, int max_obj, float* out20);
 int rt_scene_dump_instance(const rt_scene* s, int object_id, float* out17);
 /* sizes of the flattened scene: entries, triangles, instances, objects, planes, texel bytes, total device bytes */
 int rt_scene_flat_info(const rt_scene* s, int64_t out7[7]);
+/* the regrouped layout (RT_FLAG_NO_REGROUP): out8 = { has one, trees regrouped, lowest nodes in them, expected slab tests of
+ * a random line through the top-level tree and through the meshes' trees in the reference's layout, the same two in the
+ * regrouped layout, stack slots the ordered traversal needs there }; no counterpart in the reference */
+int rt_scene_regroup_info(const rt_scene* s, double out8[8]);
+/* the flattened entries of the reference's layout (regrouped = 0) or the regrouped one: 8 floats per entry (box minimum or
+ * leaf data, link; box maximum, kind — integers as bit patterns), the same leaf's entry in the other layout (-1: none) and
+ * a leaf's rank in the reference's visiting order; returns the number of entries (all arrays null: only that) */
+int rt_scene_dump_entries(const rt_scene* s, int regrouped, int max_entries, float* lo_hi8, int32_t* peer, uint32_t* rank);
 
 /* Host asset decoders on their own (Object.cpp:349-435 LoadOBJ; DataUtility.cpp:17-28,98-109 image loads). */
 int rt_load_obj(const char* path, int max_verts, float* verts8);              /* returns vertex count or <0 */

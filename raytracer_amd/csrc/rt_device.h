@@ -158,6 +158,9 @@ struct Scene {
     int top_end, stale_entry, n_planes;
     int n_entries, n_tris, n_inst, fast_div_ok, idle_entry;
     int has_fog;   // some entry is a fog volume: traversal consumes random numbers (Object.cpp:579)
+    int ranked;    // leaf entries carry their rank in the reference's visiting order (every scene without fog)
+    int has_ref;   // the entries are a regrouped layout: rays that are not ray_monotone are not walked here but handed
+                   // over to the walk through the reference's layout (rt_engine.hip, exceptions)
     // distance culling (see "distance culling" below): scene-wide constants of the bound; cull_on = 0 switches it off
     float cull_delta, cull_cabs, cull_2rmax;
     int cull_on;
@@ -381,6 +384,15 @@ __device__ __forceinline__ float recip_in_range(float d) {
 }
 __device__ __forceinline__ bool mag_in(float v, float lo, float hi) { const float a = fabsf(v); return a >= lo && a <= hi; }
 __device__ __forceinline__ bool coord_ok(float v) { return v == 0.0f || mag_in(v, 8.8817841970012523e-16f, 1.099511627776e12f); }
+// The slab test as the reference writes it (true divisions) is monotone in the box — a box that contains another is hit
+// whenever the other is — for every ray whose quotients are numbers: a direction without a zero component and nothing
+// that is not finite.  (With d = -0 the reference's test takes the entry side for the exit side; with 0 / 0 or inf - inf
+// its comparisons see NaNs.)  A regrouped layout walks only such rays; see walker_special, WALK_HANDED_OVER.
+__device__ __forceinline__ bool ray_monotone(const Ray& r) {
+    const bool finite = fabsf(r.d.x) <= FLT_MAX && fabsf(r.d.y) <= FLT_MAX && fabsf(r.d.z) <= FLT_MAX &&
+                        fabsf(r.o.x) <= FLT_MAX && fabsf(r.o.y) <= FLT_MAX && fabsf(r.o.z) <= FLT_MAX;
+    return finite && r.d.x != 0.0f && r.d.y != 0.0f && r.d.z != 0.0f;
+}
 __device__ __forceinline__ bool ray_usable(const Ray& r) {
     return mag_in(r.d.x, 9.5367431640625e-07f, 1048576.0f) && mag_in(r.d.y, 9.5367431640625e-07f, 1048576.0f) &&
            mag_in(r.d.z, 9.5367431640625e-07f, 1048576.0f) && coord_ok(r.o.x) && coord_ok(r.o.y) && coord_ok(r.o.z);
@@ -856,17 +868,14 @@ __device__ __forceinline__ void walker_start_ord(const Scene& sc, const Store& s
     w.sp = st.stack_addr + 4u * ((uint32_t)BLOCK + threadIdx.x);     // slot 1: slot 0 holds the end of the top-level list
     walker_load_ord(st, w);
 }
-// Does leaf entry a come before leaf entry b in the reference's visiting order?  Top-level entries are numbered in that
-// order; a triangle is visited when its mesh's entry is.
-__device__ inline bool rank_before(const Scene& sc, int a, int b) {
-    auto top_of = [&](int e) {
-        if (e < sc.top_end) return e;
-        const int inst = __float_as_int(sc.ent[2 * (size_t)e + 1].w);                            // triangle (or fog) entry: its instance
-        return inst >= 0 ? __float_as_int(sc.inst[(size_t)inst * rt::RT_INST_F4 + 2].w) - 1 : e;   // the instance's own entry
-    };
-    const int ta = top_of(a), tb = top_of(b);
-    return ta != tb ? ta < tb : a < b;
+// Does leaf entry a come before leaf entry b in the reference's visiting order?  Every leaf carries its rank in that
+// order in a dword its kind leaves free (a triangle in dword 0, a sphere or a cube in dword 7).  (In the reference's layout
+// kept beside a regrouped one that dword names the leaf's entry in the regrouped layout instead.)
+__device__ inline uint32_t leaf_extra(const Scene& sc, int e) {
+    const uint32_t* E = reinterpret_cast<const uint32_t*>(sc.ent) + 8 * (size_t)e;
+    return sk_kind(E[6]) == rt::ENT_TRI ? E[0] : E[7];
 }
+__device__ inline bool rank_before(const Scene& sc, int a, int b) { return leaf_extra(sc, a) < leaf_extra(sc, b); }
 // The traversal loop of the ordered traversal: box_steps (above) with the stack in place of the skip links, and with
 // the entry fetched from the LDS table or from memory, whichever the link says.  Per iteration, for the lanes that act:
 //   * lanes on an inner entry: the slab test and the culling bound as in box_steps; on a hit the far child is pushed
@@ -1041,18 +1050,19 @@ __device__ __forceinline__ uint32_t lane_now() {
 // the leaf is the one whose assignment of HitInfo.distance survives a rejection — and is finished by tri_finish_step.
 // uv_out: where a winning triangle's barycentrics go instead of the lane's registers (the second half of the ray's hit
 // record; the last triangle to win is the last to write, and no other kind of hit reads them).
-// ORD: leaves are not met in the reference's order (see "ordered traversal"): equal distances go to the leaf the
-// reference visits first, and a rejected first leaf's distance is only recorded while the ray has no hit.
-template <bool CULL, bool ORD = false>
+// Leaves need not be met in the reference's order (the ordered traversal, a regrouped layout): of two leaves at the same
+// distance the one the reference meets first wins (Object.cpp:248 keeps the earlier hit; sc.ranked: the leaves carry
+// their ranks), and a rejected first leaf's distance is recorded only while the ray has no hit — met first, as in the
+// reference, that is always so; met later, a hit stands.  RANKED = false: kernels for scenes with fog, whose leaves are
+// always met in the reference's order (and whose fog entries have no room for a rank).
+template <bool CULL, bool RANKED = true>
 __device__ __forceinline__ void closest_update(const Scene& sc, Walker& w, int e, bool ok, bool wrote, float t, float u, float v, float2* uv_out = nullptr) {
     // selects rather than branches around the updates: the record stays in registers
     bool better_ = ok && (!w.c.hit || t < w.c.dist);
-    if constexpr (ORD) { if (ok && w.c.hit && t == w.c.dist) better_ = rank_before(sc, e, w.c.best); }   // a rare tie: settled with two loads
+    if constexpr (RANKED) { if (ok && w.c.hit && t == w.c.dist && sc.ranked) better_ = rank_before(sc, e, w.c.best); }   // a rare tie: settled with two loads
     const bool better = better_;
     if (CULL && better) cull_update<CULL>(sc, w, t);
-    bool stale_ = !ok && wrote && e == w.stale;
-    if constexpr (ORD) stale_ = stale_ && !w.c.hit;
-    const bool stale = stale_;
+    const bool stale = !ok && wrote && e == w.stale && !w.c.hit;
     w.c.dist = (better || stale) ? t : w.c.dist;
     w.c.best = better ? e : w.c.best;
     if (uv_out) { if (better) *uv_out = make_float2(u, v); }
@@ -1069,7 +1079,7 @@ __device__ __forceinline__ void prim_step(const Scene& sc, const Store& st, Walk
     float t = 0;
     bool ok, wrote = false, wait = false;
     if (kind == rt::ENT_TRI) {
-        wait = tri_reach(st.tris, sk_payload(sk), cur, t) && (!w.c.hit || (ORD ? t <= w.c.dist : t < w.c.dist) || e == w.stale);
+        wait = tri_reach(st.tris, sk_payload(sk), cur, t) && (!w.c.hit || (FOG ? t < w.c.dist : t <= w.c.dist) || e == w.stale);   // (an equal distance may win by rank)
         ok = false;
     } else {
         const f2 a = E[0], b = E[1], c = E[2];
@@ -1079,7 +1089,7 @@ __device__ __forceinline__ void prim_step(const Scene& sc, const Store& st, Walk
     }
     w.reach = wait ? t : 0.0f;
     w.f0 = wait ? w.f0 : w.f1; w.f1 = wait ? w.f1 : w.f2; w.cnt -= wait ? 0u : 1u;
-    closest_update<CULL, ORD>(sc, w, e, ok, wrote, t, 0.0f, 0.0f);
+    closest_update<CULL>(sc, w, e, ok, wrote, t, 0.0f, 0.0f);
 }
 // The second part of Triangle::Intersect for a lane whose head-of-FIFO triangle is waiting for it.
 // LEAN: the alpha mask's place and size are read from the instance record instead of being carried by every lane, and
@@ -1099,7 +1109,7 @@ __device__ __forceinline__ void tri_finish_step(const Scene& sc, const Store& st
     }
     const bool ok = tri_surface(sc, st.tris, sk_payload(sk), alpha_off, alpha_wh, walker_ray(w), w.reach, t, u, v, wrote);
     w.reach = 0.0f;
-    closest_update<CULL, ORD>(sc, w, e, ok, wrote, t, u, v, LEAN ? reinterpret_cast<float2*>(hit_rec + (*idx_slot & IDX_MASK)) + 1 : nullptr);
+    closest_update<CULL>(sc, w, e, ok, wrote, t, u, v, LEAN ? reinterpret_cast<float2*>(hit_rec + (*idx_slot & IDX_MASK)) + 1 : nullptr);
 }
 // Entries that change the lane's state beyond its position; they wait until every noted leaf has been tested.  Returns
 // true when the ray has finished (closest hit known, plane list merged); the lane is idle from then on.
@@ -1115,10 +1125,14 @@ __device__ __forceinline__ void tri_finish_step(const Scene& sc, const Store& st
 // frame; installing the new ray once for the lanes going in and the lanes going out changed nothing).
 // ORD > 0: the ordered traversal with stacks of ORD-thread blocks: where the other variants follow a skip link or go
 // on behind an instance's entry, this one pops; what it leaves for later, it pushes.
+// Returns WALK_ON, WALK_DONE (the ray has finished) or WALK_HANDED_OVER: with a regrouped layout (sc.has_ref) a ray that
+// enters a mesh instance and has, in the instance's frame, a zero direction component (ray_monotone) cannot be walked
+// here; the lane goes idle and the caller hands the ray over to the walk through the reference's layout.
+enum : int { WALK_ON = 0, WALK_DONE = 1, WALK_HANDED_OVER = 2 };
 template <bool RELOAD = false, bool LEAN = false, bool SAVE = false, int ORD = 0>
-__device__ __forceinline__ bool walker_special(const Scene& sc, const Store& st, Walker& w, float4* outer_a = nullptr, float4* outer_b = nullptr, uint32_t outer_tagged = 0) {
+__device__ __forceinline__ int walker_special(const Scene& sc, const Store& st, Walker& w, float4* outer_a = nullptr, float4* outer_b = nullptr, uint32_t outer_tagged = 0) {
     const uint32_t outer_idx = outer_tagged & IDX_MASK;
-    bool done = false;
+    int done = WALK_ON;
     const int kind = sk_kind(w.sk);
     if (kind == rt::ENT_END) {
         if (w.inst >= 0) {   // PolygonMesh and its wrappers return to the top level
@@ -1139,7 +1153,7 @@ __device__ __forceinline__ bool walker_special(const Scene& sc, const Store& st,
                 if (t < w.c.dist) { w.c.hit = true; w.c.dist = t; w.c.best = -(p + 2); }
             }
             w.i = sc.idle_entry;
-            done = true;
+            done = WALK_DONE;
         }
     } else if (kind == rt::ENT_INSTANCE) {
         const int ii = sk_payload(w.sk);
@@ -1158,6 +1172,10 @@ __device__ __forceinline__ bool walker_special(const Scene& sc, const Store& st,
         w.inst = ii;
         if (!LEAN) { w.alpha_off = __float_as_int(i3.z); w.alpha_wh = __float_as_uint(i3.w); }   // alpha cut-out of the mesh's texture, or -1
         w.i = __float_as_int(i2.z);
+        if (sc.has_ref && !w.usable && !ray_monotone(walker_ray(w))) {   // not a ray for this layout: hand it over, as it was given
+            w.i = sc.idle_entry; w.inst = -1; w.cnt = 0; w.reach = 0.0f;
+            done = WALK_HANDED_OVER;
+        }
     } else {
         // an inner entry tested as the reference writes it, with true divisions: a box with min > max on some axis, or
         // a ray that is not admitted to the reciprocal path
@@ -1177,9 +1195,10 @@ __device__ __forceinline__ bool walker_special(const Scene& sc, const Store& st,
     return done;
 }
 // One round for a wave: the traversal loop; then primitive tests, repeated while at least `prim_quorum` lanes have a
-// noted leaf; then the state-changing entries of lanes that have none left.  Returns true in lanes whose ray finished.
+// noted leaf; then the state-changing entries of lanes that have none left.  Returns, per lane, what walker_special
+// returned: WALK_DONE in lanes whose ray finished, WALK_HANDED_OVER in lanes whose ray has to be walked elsewhere.
 template <bool LDS, bool FOG, bool RELOAD = false, bool SAVE = false, int ORD = 0>
-__device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Walker& w, int quorum, int prim_quorum, int finish_quorum, Prof& prof, uint32_t& n_box,
+__device__ __forceinline__ int walk_round(const Scene& sc, const Store& st, Walker& w, int quorum, int prim_quorum, int finish_quorum, Prof& prof, uint32_t& n_box,
                                            float4* outer_a = nullptr, float4* outer_b = nullptr, uint32_t outer_idx = 0, float4* hit_rec = nullptr, const uint32_t* idx_slots = nullptr) {
     RT_PROF(unsigned long long t0 = __builtin_readcyclecounter(); prof.rounds++;)
     // with few rays in the wave (the last rays of a pass) a fixed quorum is never met and every round would advance each
@@ -1213,7 +1232,7 @@ __device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Wal
     const int kind = sk_kind(w.sk);
     const bool special = w.cnt == 0 && (kind == rt::ENT_END || kind == rt::ENT_INSTANCE || kind == rt::ENT_INNER_INV ||
                                         (kind == rt::ENT_INNER && !w.usable));
-    bool done = false;
+    int done = WALK_ON;
     RT_PROF(if (__any(special)) prof.specials++;)
 #ifdef RT_PROFILE
     {
@@ -1235,11 +1254,14 @@ __device__ __forceinline__ bool walk_round(const Scene& sc, const Store& st, Wal
     return done;
 }
 // Run the lanes of a wave until all of them have finished.
+// Returns true in lanes whose ray was handed over (see walker_special) instead of finished.
 template <bool FOG>
-__device__ __forceinline__ void walk_wave_to_end(const Scene& sc, const Store& st, Walker& w) {
+__device__ __forceinline__ bool walk_wave_to_end(const Scene& sc, const Store& st, Walker& w) {
     Prof prof;
     uint32_t n_box = 0;
-    while (__any(sk_kind(w.sk) != rt::ENT_IDLE)) walk_round<false, FOG>(sc, st, w, 24, 32, 16, prof, n_box);
+    bool handed_over = false;
+    while (__any(sk_kind(w.sk) != rt::ENT_IDLE)) handed_over = (walk_round<false, FOG>(sc, st, w, 24, 32, 16, prof, n_box) == WALK_HANDED_OVER) || handed_over;
+    return handed_over;
 }
 __device__ __forceinline__ bool walker_is_idle(const Walker& w) { return sk_kind(w.sk) == rt::ENT_IDLE; }
 

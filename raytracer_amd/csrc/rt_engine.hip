@@ -55,6 +55,7 @@ constexpr int NCUR = 32, CUR_STRIDE = 1024;
 constexpr int STRIPE = 512;          // positions per stripe; range r of a queue is every NCUR-th stripe, starting with stripe r
 constexpr int COUNT_WORDS = CUR_STRIDE * (1 + NCUR);   // per batch: ray counts per pass, then NCUR rows of counters
 constexpr int BOX_COUNT_AT = 512;   // words BOX_COUNT_AT + 2k, + 2k + 1 of a batch's first row: box tests executed by pass k (64 bits)
+constexpr int EXC_COUNT_AT = 256;   // word EXC_COUNT_AT + k of a batch's first row: rays of pass k handed over to exceptions_kernel
 constexpr long long MAX_BATCHES = 4096;   // batches per frame an engine reserves pass counters for (0.5 GiB of counters at most)
 constexpr int STILE = 1024;         // shade: queue positions a block handles per round (survivors staged in 32 KiB of LDS)
 // intersect scheduling knobs (defaults in rt_engine_create; RT_REFILL_AT / RT_QUORUM / RT_CHUNK override them for tuning)
@@ -125,6 +126,7 @@ struct Queues {
     float4* a[2]; float4* b[2];      // ray records: a = (o.xyz, d.x), b = (d.y, d.z, slot, ctr | depth << 24); b[k] = a[k] + capacity
     float4* hit;                     // hit records by queue position: (distance, best entry, u, v)
     uint32_t* hit_ctr;               // scenes with fog: the path's random-number counter after the traversal
+    uint32_t* exc;                   // queue positions of the rays of the running pass that were handed over (regrouped layouts)
     uint32_t* counts;                // counts[k] = rays entering pass k
     uint32_t* cursors;               // cursors[r * CUR_STRIDE + k] = positions of range r of pass k handed out to intersect waves so far
     float4* stack;                   // [depth][slot] = (texture colour rgb, factor)
@@ -265,6 +267,12 @@ __device__ __forceinline__ T kernarg_read(size_t offset) {
 template <int N>
 __device__ __forceinline__ uint32_t* lane_slots() { __shared__ uint32_t slots[N]; return slots; }
 
+// A ray that the regrouped layout is not proven for (rt_scene.cpp, "regrouping"): its queue position goes on the list that
+// exceptions_kernel works off after the pass.  One atomic per ray: rendered frames have no such rays.
+__device__ __forceinline__ void hand_over(const Queues& q, int pass, uint32_t idx) {
+    q.exc[atomicAdd(q.counts + EXC_COUNT_AT + pass, 1u)] = idx;
+}
+
 // ---- intersect (World.cpp:105-119) ----------------------------------------------------------------------------------
 // (the parameter list is mirrored by IntersectArgs, through which kernarg_read finds cam, g and bt: change both together)
 template <bool FIRST, bool STAGED, bool FOG, int BLOCK = IBLOCK, int MIN_WAVES = 1, bool ORD = false>
@@ -359,6 +367,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, C
                             if constexpr (ORD) walker_start_ord<CULL, BLOCK>(sc, st, w, ray, rng); else walker_start<CULL>(sc, st, w, ray, rng);
                             const uint32_t tagged = RELOAD && w.usable ? idx | IDX_USABLE : idx;
                             if constexpr (LEAN) my_slot[lane_now()] = tagged; else my_idx = tagged;
+                            if (!FOG && sc.has_ref && !w.usable && !ray_monotone(ray)) { hand_over(q, pass, idx); walker_idle(sc, w); }
                         }
                     }
                 } else if (walker_is_idle(w) && o < mine_end && idx < n_in) {
@@ -367,6 +376,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, C
                         if constexpr (ORD) walker_start_ord<CULL, BLOCK>(sc, st, w, ray, rng); else walker_start<CULL>(sc, st, w, ray, rng);
                         const uint32_t tagged = RELOAD && w.usable ? idx | IDX_USABLE : idx;
                         if constexpr (LEAN) my_slot[lane_now()] = tagged; else my_idx = tagged;
+                        if (!FOG && sc.has_ref && !w.usable && !ray_monotone(ray)) { hand_over(q, pass, idx); walker_idle(sc, w); }
                     }
                 }
                 // the lean variant reads the entry every lane stands on again (it is what the lane holds already: every
@@ -389,11 +399,14 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, C
         // per SIMD was measured on both kinds of scene and gained nothing: 256-thread blocks on the 100 000-primitive
         // scene 92.9 against 92.3 ms; 640-thread blocks with the scene in LDS lose a fifth, their ten waves do not spread
         // evenly over four SIMDs.)
-        if (walk_round<STAGED, FOG, RELOAD, FIRST, ORD ? BLOCK : 0>(sc, st, w, tune.quorum, tune.prim_quorum, tune.finish_quorum, prof, n_box, q.a[qin], q.b[qin], my_idx, q.hit, my_slot)) {
+        const int ended = walk_round<STAGED, FOG, RELOAD, FIRST, ORD ? BLOCK : 0>(sc, st, w, tune.quorum, tune.prim_quorum, tune.finish_quorum, prof, n_box, q.a[qin], q.b[qin], my_idx, q.hit, my_slot);
+        if (ended == WALK_DONE) {
             // (the lean walker has written the barycentrics of its winning triangle already)
             if constexpr (LEAN) *reinterpret_cast<float2*>(q.hit + (my_slot[lane_now()] & IDX_MASK)) = make_float2(w.c.dist, __int_as_float(w.c.best));
             else q.hit[my_idx & IDX_MASK] = make_float4(w.c.dist, __int_as_float(w.c.best), w.c.u, w.c.v);
             if (FOG) q.hit_ctr[my_idx & IDX_MASK] = w.rng.ctr;
+        } else if (!FOG && ended == WALK_HANDED_OVER) {
+            if constexpr (LEAN) hand_over(q, pass, my_slot[lane_now()] & IDX_MASK); else hand_over(q, pass, my_idx & IDX_MASK);
         }
     }
     if (lane_now() == 0 && n_box) atomicAdd(reinterpret_cast<unsigned long long*>(q.counts + BOX_COUNT_AT) + pass, (unsigned long long)n_box);
@@ -409,6 +422,42 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, C
         for (int k = 0; k < 4; k++) { atomicAdd(p + 16 + k, (unsigned long long)prof.sp_exec[k]); atomicAdd(p + 20 + k, (unsigned long long)prof.sp_lanes[k]); }
     }
 #endif
+}
+
+// ---- exceptions: the rays of a pass that intersect_kernel handed over, walked through the reference's own layout -------
+// A regrouped layout (rt_scene.cpp, "regrouping") tests the leaves the reference tests for every ray for which the slab
+// test is monotone in the box (rt_device.h, ray_monotone).  The others — a direction component that is exactly zero, or
+// something that is not finite, in the scene's frame or in a mesh instance's: none among the rays of a rendered frame
+// (the lens offsets see to that), any number among a caller's own rays — are walked here, from the start, through the
+// reference's layout with the reference's slab test as written, by the same walker (scene read from memory, one ray per
+// lane until all are done).  A launch that finds no such ray leaves at once.
+// sc_ref: the reference's layout; its leaves name their entries in the regrouped layout, which is what a hit record holds.
+template <bool FIRST>
+__global__ __launch_bounds__(256) void exceptions_kernel(Scene sc_ref, Cam cam, Cfg g, Batch bt, Queues q, int pass, Debug dbg) {
+    const uint32_t n = q.counts[EXC_COUNT_AT + pass];
+    if (n == 0u || cancelled(bt)) return;
+    Store st;
+    st.ent = sc_ref.ent; st.tris = sc_ref.tris; st.inst = sc_ref.inst; st.planes = sc_ref.planes;
+    st.lds0 = nullptr; st.lds0_addr = 0; st.top_addr = 0; st.stack_addr = 0; st.root_link = 0; st.inst_end = nullptr;
+    const int qin = (pass + 1) & 1;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {   // (the same for a whole block)
+        const uint32_t k = base + threadIdx.x;
+        Walker w;
+        walker_idle(sc_ref, w);
+        uint32_t idx = 0;
+        bool have = false;
+        if (k < n) {
+            idx = q.exc[k];
+            Ray ray; Rng rng; uint32_t slot, depth;
+            have = fetch_ray<FIRST>(cam, g, bt, q, qin, dbg, idx, ray, rng, slot, depth, false);
+            if (have) walker_start<true>(sc_ref, st, w, ray, rng);
+        }
+        walk_wave_to_end<false>(sc_ref, st, w);
+        if (have) {
+            const int best = w.c.best >= 0 ? (int)leaf_extra(sc_ref, w.c.best) : w.c.best;
+            q.hit[idx] = make_float4(w.c.dist, __int_as_float(best), w.c.u, w.c.v);
+        }
+    }
 }
 
 // ---- one bounce of World::GetRayColor (World.cpp:121-170) for a ray whose closest hit is known.  Returns true when the
@@ -578,23 +627,35 @@ __global__ __launch_bounds__(256) void assemble_kernel(Cfg g, Batch bt, const ui
 // closest-hit queries for arbitrary rays (same walker, scene read from global memory; like the render kernels, compiled
 // with and without fog support, and culling by distance without it)
 template <bool FOG>
-__global__ __launch_bounds__(256) void trace_kernel(Scene sc, int n, const float* o3, const float* d3, int32_t* hit_id, float* rec9) {
+__global__ __launch_bounds__(256) void trace_kernel(Scene sc, Scene sc_ref, int n, const float* o3, const float* d3, int32_t* hit_id, float* rec9) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     Store st;
     st.ent = sc.ent; st.tris = sc.tris; st.inst = sc.inst; st.planes = sc.planes;
+    st.lds0 = nullptr; st.lds0_addr = 0; st.top_addr = 0; st.stack_addr = 0; st.root_link = 0; st.inst_end = nullptr;
     Walker w;
     walker_idle(sc, w);
     Ray r;
     r.o = mk(0, 0, 0); r.d = mk(0, 0, 1);
+    Rng rng; rng.key = (uint32_t)i; rng.ctr = 0;   // fog volumes draw random numbers: one stream per ray
+    bool elsewhere = false;   // a regrouped layout walks rays of the reciprocal path only (see exceptions_kernel)
     if (i < n) {
         r.o = mk(o3[3 * i], o3[3 * i + 1], o3[3 * i + 2]);
         r.d = mk(d3[3 * i], d3[3 * i + 1], d3[3 * i + 2]);
-        Rng rng; rng.key = (uint32_t)i; rng.ctr = 0;   // fog volumes draw random numbers: one stream per ray
         walker_start<!FOG>(sc, st, w, r, rng);
+        if (!FOG && sc.has_ref && !w.usable && !ray_monotone(r)) { elsewhere = true; walker_idle(sc, w); }
     }
-    walk_wave_to_end<FOG>(sc, st, w);
+    elsewhere = walk_wave_to_end<FOG>(sc, st, w) || elsewhere;
+    Closest c = w.c;
+    if (!FOG && sc.has_ref && __any(elsewhere)) {   // those rays again, through the reference's layout
+        Store sr = st;
+        sr.ent = sc_ref.ent; sr.inst = sc_ref.inst;
+        Walker w2;
+        walker_idle(sc_ref, w2);
+        if (elsewhere) walker_start<true>(sc_ref, sr, w2, r, rng);
+        walk_wave_to_end<false>(sc_ref, sr, w2);
+        if (elsewhere) { c = w2.c; if (c.best >= 0) c.best = (int)leaf_extra(sc_ref, c.best); }
+    }
     if (i >= n) return;
-    const Closest& c = w.c;
     float* q = rec9 + 9 * (size_t)i;
     q[0] = c.dist;
     if (!c.hit) { hit_id[i] = -1; for (int k = 1; k < 9; k++) q[k] = 0; return; }
@@ -713,6 +774,7 @@ struct rt_engine {
     bool frame_dirty = true;            // the frame buffer differs from h_frame (true from the start: h_frame is allocated uninitialised,
                                         // and the first complete map must copy the zeroed frame buffer, FrameManager.cpp:13)
     Scene sc{};
+    Scene sc_ref{};                     // the reference's layout of the same scene when `sc` is the regrouped one (sc.has_ref)
     OrdScene os{};
     bool have_scene = false, have_camera = false;
     Cam cam{};
@@ -848,6 +910,10 @@ int run_passes(rt_engine* e, const Batch& bt, hipStream_t st, uint32_t* counts, 
         if (first) launch_intersect<true>(e, st, g, bt, q, pass);
         else launch_intersect<false>(e, st, g, bt, q, pass);
         if (e->time_kernels) (void)hipEventRecord(next_event(e), st);
+        if (e->sc.has_ref) {   // the rays the pass handed over (none in a rendered frame: the launch leaves at once)
+            if (first) hipLaunchKernelGGL(exceptions_kernel<true>, dim3(64), dim3(256), 0, st, e->sc_ref, e->cam, g, bt, q, pass, e->dbg);
+            else hipLaunchKernelGGL(exceptions_kernel<false>, dim3(64), dim3(256), 0, st, e->sc_ref, e->cam, g, bt, q, pass, e->dbg);
+        }
         if (first) {
             const uint32_t n = (uint32_t)bt.n_pixels * (uint32_t)(g.S * g.S);
             const int blocks = (int)std::min<uint32_t>((n + 255u) / 256u, (uint32_t)shade_blocks);
@@ -941,6 +1007,7 @@ int init_engine(rt_engine* e, const rt_config* cfg) {
     }
     HIP_TRY(hipMalloc((void**)&e->q.hit, cap * sizeof(float4)));
     HIP_TRY(hipMalloc((void**)&e->q.hit_ctr, cap * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc((void**)&e->q.exc, cap * sizeof(uint32_t)));      // (every ray of a pass may be handed over: a caller's own rays)
     HIP_TRY(hipMalloc((void**)&e->q.stack, cap * sizeof(float4) * (size_t)std::max(1, cfg->bounces)));
     HIP_TRY(hipMalloc((void**)&e->q.radiance, cap * sizeof(float4)));
     HIP_TRY(hipMalloc((void**)&e->d_frame, (size_t)cfg->width * cfg->height * 4));
@@ -992,7 +1059,7 @@ void rt_engine_destroy(rt_engine* e) {
     (void)wait_all(e);
     free_scene(e);
     for (int k = 0; k < 2; k++) (void)hipFree(e->q.a[k]);   // (b[k] is its second half)
-    (void)hipFree(e->q.hit); (void)hipFree(e->q.hit_ctr);
+    (void)hipFree(e->q.hit); (void)hipFree(e->q.hit_ctr); (void)hipFree(e->q.exc);
     (void)hipFree(e->q.stack); (void)hipFree(e->q.radiance); (void)hipFree(e->d_frame); (void)hipFree(e->d_counts_all);
     (void)hipFree(e->dbg.primary_id); (void)hipFree(e->dbg.primary_t); (void)hipFree(e->dbg.rng_draws);
     for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
@@ -1011,6 +1078,67 @@ int rt_engine_get_config(const rt_engine* e, rt_config* out) {
     return RT_OK;
 }
 
+// Device entries of one layout (rt_flat.h): 8 dwords each.  A leaf carries one more number in a dword its kind leaves
+// free (sphere, cube: dword 7; triangle: dword 0; a fog volume has none, and scenes with fog need none): its rank in the
+// reference's visiting order (what settles equal distances), or, in the reference's layout when the engine renders from
+// the regrouped one, the leaf's entry there (`leaf_peer`: what the walk of an exceptional ray reports).
+static std::vector<rt::F4> device_entries(const rt_layout& L, bool leaf_peer, bool& has_fog) {
+    std::vector<rt::F4> inter(L.ent_lo.size() * 2);
+    for (size_t i = 0; i < L.ent_lo.size(); i++) {
+        const rt::F4 lo = L.ent_lo[i], hi = L.ent_hi[i];
+        const int kind = rt::bits_i(hi.w);
+        auto tag = [](int k, int payload) { return rt::bits_f((int32_t)(((uint32_t)k << rt::SK_SHIFT) | (uint32_t)payload)); };
+        const float extra = rt::bits_f(leaf_peer ? L.ent_peer[i] : (int32_t)L.ent_rank[i]);
+        rt::F4 a{0, 0, 0, 0}, b{0, 0, tag(kind, 0), 0};
+        switch (kind) {
+        case rt::ENT_INNER:
+            a = {lo.x, hi.x, lo.y, hi.y};
+            if (lo.x <= hi.x && lo.y <= hi.y && lo.z <= hi.z) b = {lo.z, hi.z, lo.w, L.ent_rho[i]};
+            else b = {lo.z, hi.z, tag(rt::ENT_INNER_INV, 0), lo.w};
+            break;
+        case rt::ENT_SPHERE: a = lo; b.z = tag(kind, rt::bits_i(hi.x)); b.w = extra; break;
+        case rt::ENT_CUBE: a = {lo.x, lo.y, lo.z, hi.x}; b = {hi.y, hi.z, tag(kind, rt::bits_i(lo.w)), extra}; break;
+        case rt::ENT_FOG: a = {lo.x, lo.y, lo.z, hi.x}; b = {hi.y, hi.z, tag(kind, rt::bits_i(lo.w)), rt::bits_f(-1)}; has_fog = true; break;
+        case rt::ENT_TRI: a.x = extra; b.z = tag(kind, rt::bits_i(lo.x)); break;
+        case rt::ENT_INSTANCE: b.z = tag(kind, rt::bits_i(lo.x)); break;
+        default: break;
+        }
+        inter[2 * i] = a; inter[2 * i + 1] = b;
+    }
+    // a triangle or fog entry names the instance it belongs to (every instance has its own range of entries)
+    for (size_t k = 0; k + rt::RT_INST_F4 <= L.inst.size(); k += rt::RT_INST_F4)
+        for (int i = rt::bits_i(L.inst[k + 2].z); i < rt::bits_i(L.inst[k + 2].w); i++) {
+            const int kind = rt::bits_i(L.ent_hi[i].w);
+            if (kind == rt::ENT_TRI || kind == rt::ENT_FOG) inter[2 * (size_t)i + 1].w = rt::bits_f((int)(k / rt::RT_INST_F4));
+        }
+    return inter;
+}
+// Device instance records of one layout: the host's, with the alpha mask of the mesh's image texture (so that entering
+// an instance needs no look-up in the object table) and, in place of the end of the instance's range, the entry behind
+// the instance's own entry in the top-level list, where a ray goes on when it leaves the instance.
+static int device_instances(const rt_layout& L, const rt_scene_flat* f, const std::vector<int>& alpha_at, std::vector<rt::F4>& inst_rec) {
+    inst_rec = L.inst;
+    for (size_t k = 0; k + rt::RT_INST_F4 <= inst_rec.size(); k += rt::RT_INST_F4) {
+        const rt::F4 ob = f->objects[(size_t)rt::bits_i(inst_rec[k + 3].x) * rt::RT_OBJ_F4];
+        int at = -1;
+        uint32_t wh = 0;
+        if (rt::bits_i(ob.y) == RT_TEX_IMAGE) {
+            const int img = rt::bits_i(ob.z);
+            if (alpha_at[img] < 0) return fail(RT_E_INVALID, "image textures must be RGBA and at most 65535 texels wide and high");
+            at = alpha_at[img];
+            wh = (f->images[img].h << 16) | f->images[img].w;
+        }
+        inst_rec[k + 3].z = rt::bits_f(at);
+        inst_rec[k + 3].w = rt::bits_f((int32_t)wh);
+    }
+    for (int i = 0; i < L.top_end; i++)
+        if (rt::bits_i(L.ent_hi[i].w) == rt::ENT_INSTANCE) {
+            const size_t k = (size_t)rt::bits_i(L.ent_lo[i].x) * rt::RT_INST_F4;
+            if (k + rt::RT_INST_F4 <= inst_rec.size()) inst_rec[k + 2].w = rt::bits_f(i + 1);
+        }
+    return RT_OK;
+}
+
 static int rt_engine_set_scene_impl(rt_engine* e, const rt_scene* s) {
     if (!e) return fail(RT_E_INVALID, "null engine");
     const rt_scene_flat* f = rt_scene_get_flat(s);
@@ -1018,41 +1146,18 @@ static int rt_engine_set_scene_impl(rt_engine* e, const rt_scene* s) {
     HIP_TRY(hipSetDevice(e->cfg.device));
     if (int rc = wait_all(e)) return rc;
     free_scene(e);
+    // the layout the kernels walk: the regrouped one when the scene has it, else the reference's
+    const bool use_fast = f->has_fast && !(e->cfg.flags & RT_FLAG_NO_REGROUP);
+    const rt_layout& L = use_fast ? f->fast : static_cast<const rt_layout&>(*f);
     Scene sc{};
     float4 *ent, *tris, *inst, *objects, *planes;
     rt::ImageRec* images;
     uint8_t* texels;
-    // device entries (layout: rt_flat.h), 8 dwords each
     // the traversal addresses entries with 32-bit byte offsets (32 bytes each) and texels with 32-bit offsets
-    if (f->ent_lo.size() >= (1u << 27) || f->objects.size() / rt::RT_OBJ_F4 > rt::SK_MASK) return fail(RT_E_INVALID, "scene too large: 2^27 entries or more, or more than 2^28 objects");
+    if (L.ent_lo.size() >= (1u << 27) || f->objects.size() / rt::RT_OBJ_F4 > rt::SK_MASK) return fail(RT_E_INVALID, "scene too large: 2^27 entries or more, or more than 2^28 objects");
     if (f->texels.size() >= ((size_t)1 << 32)) return fail(RT_E_INVALID, "scene too large: 4 GiB of texels or more");
-    std::vector<rt::F4> inter(f->ent_lo.size() * 2);
     bool has_fog = false;
-    for (size_t i = 0; i < f->ent_lo.size(); i++) {
-        const rt::F4 lo = f->ent_lo[i], hi = f->ent_hi[i];
-        const int kind = rt::bits_i(hi.w);
-        auto tag = [](int k, int payload) { return rt::bits_f((int32_t)(((uint32_t)k << rt::SK_SHIFT) | (uint32_t)payload)); };
-        rt::F4 a{0, 0, 0, 0}, b{0, 0, tag(kind, 0), 0};
-        switch (kind) {
-        case rt::ENT_INNER:
-            a = {lo.x, hi.x, lo.y, hi.y};
-            if (lo.x <= hi.x && lo.y <= hi.y && lo.z <= hi.z) b = {lo.z, hi.z, lo.w, f->ent_rho[i]};
-            else b = {lo.z, hi.z, tag(rt::ENT_INNER_INV, 0), lo.w};
-            break;
-        case rt::ENT_SPHERE: a = lo; b.z = tag(kind, rt::bits_i(hi.x)); break;
-        case rt::ENT_CUBE: a = {lo.x, lo.y, lo.z, hi.x}; b = {hi.y, hi.z, tag(kind, rt::bits_i(lo.w)), 0}; break;
-        case rt::ENT_FOG: a = {lo.x, lo.y, lo.z, hi.x}; b = {hi.y, hi.z, tag(kind, rt::bits_i(lo.w)), rt::bits_f(-1)}; has_fog = true; break;
-        case rt::ENT_TRI: case rt::ENT_INSTANCE: b.z = tag(kind, rt::bits_i(lo.x)); break;
-        default: break;
-        }
-        inter[2 * i] = a; inter[2 * i + 1] = b;
-    }
-    // a triangle or fog entry names the instance it belongs to (every instance has its own range of entries)
-    for (size_t k = 0; k + rt::RT_INST_F4 <= f->inst.size(); k += rt::RT_INST_F4)
-        for (int i = rt::bits_i(f->inst[k + 2].z); i < rt::bits_i(f->inst[k + 2].w); i++) {
-            const int kind = rt::bits_i(f->ent_hi[i].w);
-            if (kind == rt::ENT_TRI || kind == rt::ENT_FOG) inter[2 * (size_t)i + 1].w = rt::bits_f((int)(k / rt::RT_INST_F4));
-        }
+    std::vector<rt::F4> inter = device_entries(L, false, has_fog);
     if (int rc = upload(&ent, inter.data(), inter.size() * 16)) return rc;
     e->scene_allocs.push_back(ent);
     // device triangles carry the two edges Triangle::Intersect starts from (Object.cpp:503-504: the same float
@@ -1084,29 +1189,8 @@ static int rt_engine_set_scene_impl(rt_engine* e, const rt_scene* s) {
             if (byte < f->texels.size() && f->texels[byte] >= 1) alpha_bits[(size_t)alpha_at[k] + (t >> 5)] |= 1u << (t & 31);
         }
     }
-    // instance records get the alpha mask of the mesh's image texture, so that entering an instance needs no look-up
-    // in the object table
-    std::vector<rt::F4> inst_rec(f->inst);
-    for (size_t k = 0; k + rt::RT_INST_F4 <= inst_rec.size(); k += rt::RT_INST_F4) {
-        const rt::F4 ob = f->objects[(size_t)rt::bits_i(inst_rec[k + 3].x) * rt::RT_OBJ_F4];
-        int at = -1;
-        uint32_t wh = 0;
-        if (rt::bits_i(ob.y) == RT_TEX_IMAGE) {
-            const int img = rt::bits_i(ob.z);
-            if (alpha_at[img] < 0) return fail(RT_E_INVALID, "image textures must be RGBA and at most 65535 texels wide and high");
-            at = alpha_at[img];
-            wh = (f->images[img].h << 16) | f->images[img].w;
-        }
-        inst_rec[k + 3].z = rt::bits_f(at);
-        inst_rec[k + 3].w = rt::bits_f((int32_t)wh);
-    }
-    // ... and the index of the entry behind the instance's own entry in the top-level list, where a ray goes on when it
-    // leaves the instance (in place of the end of the instance's range, which only the host needs)
-    for (int i = 0; i < f->top_end; i++)
-        if (rt::bits_i(f->ent_hi[i].w) == rt::ENT_INSTANCE) {
-            const size_t k = (size_t)rt::bits_i(f->ent_lo[i].x) * rt::RT_INST_F4;
-            if (k + rt::RT_INST_F4 <= inst_rec.size()) inst_rec[k + 2].w = rt::bits_f(i + 1);
-        }
+    std::vector<rt::F4> inst_rec;
+    if (int rc = device_instances(L, f, alpha_at, inst_rec)) return rc;
     uint32_t* d_alpha;
     if (int rc = upload(&d_alpha, alpha_bits.data(), alpha_bits.size() * 4)) return rc;
     e->scene_allocs.push_back(d_alpha);
@@ -1124,22 +1208,45 @@ static int rt_engine_set_scene_impl(rt_engine* e, const rt_scene* s) {
     sc.ent = ent; sc.tris = tris; sc.inst = inst; sc.objects = objects; sc.planes = planes;
     sc.images = images; sc.texels = texels;
     sc.sky_off = f->sky.offset; sc.sky_w = f->sky.w; sc.sky_h = f->sky.h;
-    sc.top_end = f->top_end; sc.stale_entry = f->stale_entry; sc.n_planes = (int)f->planes.size();
-    sc.n_entries = (int)f->ent_lo.size(); sc.n_tris = (int)f->tris.size() / rt::RT_TRI_F4; sc.n_inst = (int)f->inst.size() / rt::RT_INST_F4; sc.fast_div_ok = f->fast_div_ok ? 1 : 0;
-    sc.idle_entry = f->idle_entry;
+    sc.top_end = L.top_end; sc.stale_entry = L.stale_entry; sc.n_planes = (int)f->planes.size();
+    sc.n_entries = (int)L.ent_lo.size(); sc.n_tris = (int)f->tris.size() / rt::RT_TRI_F4; sc.n_inst = (int)L.inst.size() / rt::RT_INST_F4; sc.fast_div_ok = f->fast_div_ok ? 1 : 0;
+    sc.idle_entry = L.idle_entry;
     sc.has_fog = has_fog ? 1 : 0;
+    sc.ranked = has_fog ? 0 : 1;
+    sc.has_ref = use_fast ? 1 : 0;
     sc.cull_delta = f->cull_delta; sc.cull_cabs = f->cull_cabs; sc.cull_2rmax = f->cull_2rmax;
     sc.cull_on = (e->cfg.flags & RT_FLAG_NO_CULL) ? 0 : 1;
+    // The reference's own layout beside a regrouped one: rays that the regrouped hierarchy is not proven for (a zero
+    // direction component, in the scene's frame or in a mesh instance's) are walked through it by exceptions_kernel; its
+    // leaves name their entries in the regrouped layout, which is what hit records hold.
+    e->sc_ref = Scene{};
+    if (use_fast) {
+        bool fog_ref = false;
+        std::vector<rt::F4> inter_ref = device_entries(*f, true, fog_ref);
+        std::vector<rt::F4> inst_ref;
+        if (int rc = device_instances(*f, f, alpha_at, inst_ref)) return rc;
+        float4 *d_ent_ref, *d_inst_ref;
+        if (int rc = upload(&d_ent_ref, inter_ref.data(), inter_ref.size() * 16)) return rc;
+        e->scene_allocs.push_back(d_ent_ref);
+        if (int rc = upload(&d_inst_ref, inst_ref.data(), inst_ref.size() * 16)) return rc;
+        e->scene_allocs.push_back(d_inst_ref);
+        Scene r = sc;
+        r.ent = d_ent_ref; r.inst = d_inst_ref;
+        r.top_end = f->top_end; r.stale_entry = f->stale_entry; r.n_entries = (int)f->ent_lo.size(); r.n_inst = (int)f->inst.size() / rt::RT_INST_F4;
+        r.idle_entry = f->idle_entry;
+        r.ranked = 0; r.has_ref = 0;      // met in the reference's order: the first of two equal distances is the one to keep
+        e->sc_ref = r;
+    }
     // stage the whole scene in LDS when two 512-thread blocks per CU can each hold it (160 KiB per CU)
-    const size_t need = (inter.size() + f->tris.size() + f->inst.size() + f->planes.size()) * 16;
+    const size_t need = (inter.size() + f->tris.size() + L.inst.size() + f->planes.size()) * 16;
     e->staged_bytes = (need <= (size_t)MAX_STAGED_BYTES && !(e->cfg.flags & RT_FLAG_NO_LDS)) ? need : 0;
     // Otherwise, without fog: the ordered traversal, if a ray's stack fits (layout of its entries and table: rt_flat.h)
     e->ord_bytes = 0;
     e->os = OrdScene{};
-    const size_t stack_bytes = (size_t)f->stack_need * OBLOCK * 4;
-    if (!e->staged_bytes && !has_fog && !(e->cfg.flags & RT_FLAG_NO_ORDER) && f->ent_lo.size() < rt::LINK_LDS && stack_bytes + 4096 <= (size_t)MAX_ORD_BYTES) {
-        const size_t n = f->ent_lo.size();
-        auto is_plain_inner = [&](size_t i) { return rt::bits_i(f->ent_hi[i].w) == rt::ENT_INNER && rt::bits_i(inter[2 * i + 1].z) >> rt::SK_SHIFT == rt::ENT_INNER; };
+    const size_t stack_bytes = (size_t)L.stack_need * OBLOCK * 4;
+    if (!e->staged_bytes && !has_fog && !(e->cfg.flags & RT_FLAG_NO_ORDER) && L.ent_lo.size() < rt::LINK_LDS && stack_bytes + 4096 <= (size_t)MAX_ORD_BYTES) {
+        const size_t n = L.ent_lo.size();
+        auto is_plain_inner = [&](size_t i) { return rt::bits_i(L.ent_hi[i].w) == rt::ENT_INNER && rt::bits_i(inter[2 * i + 1].z) >> rt::SK_SHIFT == rt::ENT_INNER; };
         // the upper levels of the top-level tree, level by level, as many whole levels as fit beside the stacks
         std::vector<int32_t> table, level;               // entry indices: in the table, in the level being tried
         if (is_plain_inner(0)) level.push_back(0);
@@ -1148,7 +1255,7 @@ static int rt_engine_set_scene_impl(rt_engine* e, const rt_scene* s) {
             table.insert(table.end(), level.begin(), level.end());
             std::vector<int32_t> next;
             for (int32_t i : level)
-                for (int32_t c : {i + 1, f->ent_right[i]})
+                for (int32_t c : {i + 1, L.ent_right[i]})
                     if (c >= 0 && is_plain_inner((size_t)c)) next.push_back(c);
             level.swap(next);
         }
@@ -1160,12 +1267,12 @@ static int rt_engine_set_scene_impl(rt_engine* e, const rt_scene* s) {
         auto rho_axis = [&](size_t i) {
             uint32_t b = (uint32_t)rt::bits_i(inter[2 * i + 1].w);
             if (b < 0x7F800000u) b = (b + 3u) & ~3u;
-            return (b & ~3u) | (uint32_t)f->ent_axis[i];
+            return (b & ~3u) | (uint32_t)L.ent_axis[i];
         };
         std::vector<rt::F4> ord(inter);
         for (size_t i = 0; i < n; i++) {
-            if (rt::bits_i(f->ent_hi[i].w) != rt::ENT_INNER) continue;
-            const uint32_t second = link_of(f->ent_right[i]);
+            if (rt::bits_i(L.ent_hi[i].w) != rt::ENT_INNER) continue;
+            const uint32_t second = link_of(L.ent_right[i]);
             if (is_plain_inner(i)) { ord[2 * i + 1].z = rt::bits_f((int32_t)second); ord[2 * i + 1].w = rt::bits_f((int32_t)rho_axis(i)); }
             else ord[2 * i + 1].w = rt::bits_f((int32_t)second);          // INNER_INV: kind in dword 6, the link in dword 7
         }
@@ -1176,8 +1283,8 @@ static int rt_engine_set_scene_impl(rt_engine* e, const rt_scene* s) {
             memcpy(r, &ord[2 * i], 32);
             r[8] = link_of((int32_t)i + 1);
         }
-        std::vector<int32_t> inst_end(std::max<size_t>(1, f->inst.size() / rt::RT_INST_F4), 0);
-        for (size_t k = 0; k + rt::RT_INST_F4 <= f->inst.size(); k += rt::RT_INST_F4) inst_end[k / rt::RT_INST_F4] = rt::bits_i(f->inst[k + 2].w);
+        std::vector<int32_t> inst_end(std::max<size_t>(1, L.inst.size() / rt::RT_INST_F4), 0);
+        for (size_t k = 0; k + rt::RT_INST_F4 <= L.inst.size(); k += rt::RT_INST_F4) inst_end[k / rt::RT_INST_F4] = rt::bits_i(L.inst[k + 2].w);
         float4* d_ord; uint32_t* d_tab; int32_t* d_end;
         if (int rc = upload(&d_ord, ord.data(), ord.size() * 16)) return rc;
         e->scene_allocs.push_back(d_ord);
@@ -1186,7 +1293,7 @@ static int rt_engine_set_scene_impl(rt_engine* e, const rt_scene* s) {
         if (int rc = upload(&d_end, inst_end.data(), inst_end.size() * 4)) return rc;
         e->scene_allocs.push_back(d_end);
         e->os.ent_ord = d_ord; e->os.top_tab = d_tab; e->os.inst_end = d_end;
-        e->os.n_top_tab = (int)table.size(); e->os.stack_slots = f->stack_need; e->os.root_link = link_of(0);
+        e->os.n_top_tab = (int)table.size(); e->os.stack_slots = L.stack_need; e->os.root_link = link_of(0);
         e->ord_bytes = stack_bytes + tab.size() * 4;
     }
     e->sc = sc;
@@ -1433,8 +1540,8 @@ int rt_engine_trace(rt_engine* e, int n, const float* o3, const float* d3, int32
         if (hipMalloc((void**)&d_hit, (size_t)n * 4) != hipSuccess || hipMalloc((void**)&d_rec, (size_t)n * 36) != hipSuccess)
             rc = fail(RT_E_NOMEM, "device allocation failed");
         else {
-            if (e->sc.has_fog) hipLaunchKernelGGL(trace_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->sc, n, d_o, d_d, d_hit, d_rec);
-            else hipLaunchKernelGGL(trace_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->sc, n, d_o, d_d, d_hit, d_rec);
+            if (e->sc.has_fog) hipLaunchKernelGGL(trace_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->sc, e->sc_ref, n, d_o, d_d, d_hit, d_rec);
+            else hipLaunchKernelGGL(trace_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->sc, e->sc_ref, n, d_o, d_d, d_hit, d_rec);
             hipError_t he = hipStreamSynchronize(e->stream);
             if (he != hipSuccess) rc = fail(RT_E_DEVICE, hipGetErrorString(he));
             else {
@@ -1472,8 +1579,8 @@ int rt_engine_trace_static(rt_engine* e, int n, const float* o3, const float* d3
     memcpy(host + AT_D, d3, (size_t)n * 12);
     HIP_TRY(hipMemcpyAsync(d_o, host, (size_t)n * 12, hipMemcpyHostToDevice, e->stream));
     HIP_TRY(hipMemcpyAsync(d_d, host + AT_D, (size_t)n * 12, hipMemcpyHostToDevice, e->stream));
-    if (e->sc.has_fog) hipLaunchKernelGGL(trace_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->sc, n, d_o, d_d, d_hit, d_rec);
-    else hipLaunchKernelGGL(trace_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->sc, n, d_o, d_d, d_hit, d_rec);
+    if (e->sc.has_fog) hipLaunchKernelGGL(trace_kernel<true>, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->sc, e->sc_ref, n, d_o, d_d, d_hit, d_rec);
+    else hipLaunchKernelGGL(trace_kernel<false>, dim3((n + 255) / 256), dim3(256), 0, e->stream, e->sc, e->sc_ref, n, d_o, d_d, d_hit, d_rec);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(host + AT_HIT, d_hit, (size_t)n * 4, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipMemcpyAsync(host + AT_REC, d_rec, (size_t)n * 36, hipMemcpyDeviceToHost, e->stream));

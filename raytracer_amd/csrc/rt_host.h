@@ -57,30 +57,45 @@ bool load_png(const std::string& path, int req_channels, bool flip, std::vector<
 
 }  // namespace rt
 
-// The flattened scene as the engine uploads it (layout: rt_flat.h).
-struct rt_scene_flat {
+// One arrangement of a scene's entries (layout: rt_flat.h).  A flattened scene has the reference's arrangement — every
+// tree in the order BVH_Node::Intersect (Object.cpp:241-252) walks it — and may have a second one, `fast`, in which the
+// levels of a tree ABOVE its lowest nodes are rebuilt (rt_scene.cpp, "regrouping"); leaves, lowest nodes, instances and
+// triangles are the same objects in both.
+struct rt_layout {
     std::vector<rt::F4> ent_lo, ent_hi;      // threaded preorder entries
-    std::vector<rt::F4> tris;                // RT_TRI_F4 float4 per triangle
-    std::vector<rt::F4> inst;                // RT_INST_F4 float4 per mesh instance
-    std::vector<rt::F4> objects;             // RT_OBJ_F4 float4 per object id
-    std::vector<rt::F4> planes;              // (y, object id bits, 0, 0)
-    std::vector<rt::ImageRec> images;
-    std::vector<uint8_t> texels;             // all images then the skybox, each padded by one row
-    rt::ImageRec sky{0, 0, 0, 0};
+    std::vector<rt::F4> inst;                // RT_INST_F4 float4 per mesh instance (entry ranges and stale entries are the layout's own)
     int32_t top_end = 0, stale_entry = -1, idle_entry = 0;
-    bool fast_div_ok = false;                // every box coordinate is 0 or has magnitude in [2^-50, 2^40] (see rt_device.h, div_by)
     // Distance culling (rt_device.h, "distance culling"): per entry, for inner entries of the top level, the largest
     // 1 / (2 radius) over the spheres below it (0 when only cubes are below), or +inf when something below may not be
-    // culled (a mesh instance, a fog volume, a sphere with a negative radius, a cube with min > max); and the
-    // scene-wide constants of the bound.
+    // culled (a mesh instance, a fog volume, a sphere with a negative radius, a cube with min > max).
     std::vector<float> ent_rho;
-    float cull_delta = 0, cull_cabs = 0, cull_2rmax = 0;
     // Ordered traversal: per inner entry the index of its second child's entry (the first child is the next entry; -1
     // when the node lists a single child) and the axis along which the first child's box starts no later than the
     // second's (3 for a single child); and the stack slots a ray can need at most.
     std::vector<int32_t> ent_right;
     std::vector<uint8_t> ent_axis;
     int32_t stack_need = 0;
+    // Leaf entries (sphere, cube, fog, triangle): the entry of the same leaf in the scene's other layout (-1 when there
+    // is none), and the leaf's place in the order in which the reference meets the scene's leaves (ties between equal
+    // distances go to the leaf met first, Object.cpp:248).  0 / -1 for other kinds of entries.
+    std::vector<int32_t> ent_peer;
+    std::vector<uint32_t> ent_rank;
+};
+
+// The flattened scene as the engine uploads it: the reference's layout (the base), what both layouts share, and the
+// regrouped layout when the scene has one.
+struct rt_scene_flat : rt_layout {
+    std::vector<rt::F4> tris;                // RT_TRI_F4 float4 per triangle
+    std::vector<rt::F4> objects;             // RT_OBJ_F4 float4 per object id
+    std::vector<rt::F4> planes;              // (y, object id bits, 0, 0)
+    std::vector<rt::ImageRec> images;
+    std::vector<uint8_t> texels;             // all images then the skybox, each padded by one row
+    rt::ImageRec sky{0, 0, 0, 0};
+    bool fast_div_ok = false;                // every box coordinate is 0 or has magnitude in [2^-50, 2^40] (see rt_device.h, div_by)
+    float cull_delta = 0, cull_cabs = 0, cull_2rmax = 0;   // scene-wide constants of the culling bound
+    bool has_fast = false;                   // `fast` is filled: some tree of the scene was regrouped
+    rt_layout fast;
+    int32_t regrouped_trees = 0, regrouped_groups = 0;
 };
 
 const rt_scene_flat* rt_scene_get_flat(const struct rt_scene* s);

@@ -232,67 +232,281 @@ void finish_rotation(rt_scene& s, int idx) {
     o.box = {mn + o.pivot, mx + o.pivot};
 }
 
+// ------------------------------------------------------------------------------------------------- regrouping
+// What the levels of a tree above its lowest nodes are for.  BVH_Node::Intersect (Object.cpp:241-252) tests a leaf when
+// the boxes of ALL nodes above it are hit.  Every node's box is the fmin / fmax union of its children's boxes
+// (Object.cpp:156-166), hence contains, coordinate by coordinate, the box of every node below it, and
+// BoundingBox::DoesRayHit (DataUtility.cpp:35-82) is monotone in the box: a subtraction and a division by the same
+// direction component round monotonically, so a larger box gets entry distances that are no larger and exit distances
+// that are no smaller, and none of the test's comparisons can reject the larger box when it accepts the smaller one.
+// (This needs boxes with min <= max and a ray whose quotients are numbers: no zero direction component, nothing that is
+// not finite.  Trees with other boxes are left alone, and other rays are walked through the reference's own arrangement:
+// rt_device.h ray_monotone, rt_engine.hip exceptions_kernel.)
+// So a leaf is tested exactly when the box of its LOWEST node — the node whose children are leaves — is hit, and the
+// levels above decide nothing: they only save work.  The reference builds them with a random axis and a median cut
+// (Object.cpp:191-216); a regrouped layout keeps every lowest node with its own box and its leaves, and rebuilds the
+// levels above with boxes that are unions again (so the same monotonicity makes the new hierarchy visit every lowest
+// node whose box is hit): small trees bottom-up, always joining the two clusters whose union has the smallest surface;
+// large ones cut top-down by the surface-area heuristic into parts that are then joined bottom-up.  What depended on
+// the order of the visits — which of two leaves at the same distance wins, and the rejected first leaf whose
+// HitInfo.distance survives — is settled by each leaf's rank in the reference's order (rt_device.h, closest_update).
+struct Regroup {
+    const rt_scene& s;
+    struct FNode { Box3 box; int a, b; };   // children: >= 0 another FNode, < 0 the group ~child
+    std::vector<int> groups;                // the tree's lowest nodes (object indices), in the reference's order
+    std::vector<FNode> nodes;
+    int root = -1;
+    int JOIN_MAX = 256;                     // clusters of at most this many groups are joined bottom-up (RT_JOIN_MAX: experiments)
+
+    static bool ordered(const Box3& b) {
+        for (int c = 0; c < 3; c++)
+            if (!(b.mn[c] <= b.mx[c]) || !(std::fabs(b.mn[c]) <= FLT_MAX) || !(std::fabs(b.mx[c]) <= FLT_MAX)) return false;
+        return true;
+    }
+    // the lowest nodes of the tree under idx; false when the tree cannot be regrouped (a box with min > max, or a
+    // node with a leaf beside a subtree)
+    bool collect(int idx) {
+        const Obj& o = s.objs[idx];
+        if (o.kind != NODE || !ordered(o.box)) return false;
+        const bool ln = s.objs[o.left].kind == NODE, rn = s.objs[o.right].kind == NODE;
+        if (!ln && !rn) { groups.push_back(idx); return true; }
+        if (ln != rn) return false;
+        return collect(o.left) && collect(o.right);
+    }
+    const Box3& box_of_child(int child) const { return child < 0 ? s.objs[groups[(size_t)~child]].box : nodes[(size_t)child].box; }
+    static Box3 unite(const Box3& a, const Box3& b) {
+        return {{std::fmin(a.mn.x, b.mn.x), std::fmin(a.mn.y, b.mn.y), std::fmin(a.mn.z, b.mn.z)},
+                {std::fmax(a.mx.x, b.mx.x), std::fmax(a.mx.y, b.mx.y), std::fmax(a.mx.z, b.mx.z)}};
+    }
+    static double area(const Box3& b) {
+        const double x = (double)b.mx.x - b.mn.x, y = (double)b.mx.y - b.mn.y, z = (double)b.mx.z - b.mn.z;
+        return x * y + y * z + x * z;
+    }
+    int join(int a, int b) {
+        nodes.push_back({unite(box_of_child(a), box_of_child(b)), a, b});
+        return (int)nodes.size() - 1;
+    }
+    // bottom-up: join the two clusters whose union has the smallest surface until one is left
+    int agglomerate(std::vector<int> code) {
+        const int n = (int)code.size();
+        if (n == 1) return code[0];
+        std::vector<Box3> box((size_t)n);
+        std::vector<char> active((size_t)n, 1);
+        std::vector<int> best((size_t)n, -1);
+        std::vector<double> cost((size_t)n, 0.0);
+        for (int i = 0; i < n; i++) box[i] = box_of_child(code[i]);
+        auto find_best = [&](int i) {
+            best[i] = -1;
+            cost[i] = std::numeric_limits<double>::infinity();
+            for (int j = 0; j < n; j++) {
+                if (j == i || !active[j]) continue;
+                const double c = area(unite(box[i], box[j]));
+                if (c < cost[i]) { cost[i] = c; best[i] = j; }
+            }
+        };
+        for (int i = 0; i < n; i++) find_best(i);
+        for (int left = n; left > 1; left--) {
+            int i = -1;
+            for (int k = 0; k < n; k++)
+                if (active[k] && (i < 0 || cost[k] < cost[i])) i = k;
+            const int j = best[i];
+            code[i] = join(code[i], code[j]);
+            box[i] = nodes[(size_t)code[i]].box;
+            active[j] = 0;
+            if (left == 2) return code[i];
+            find_best(i);
+            for (int k = 0; k < n; k++) {
+                if (!active[k] || k == i) continue;
+                if (best[k] == i || best[k] == j) find_best(k);
+                else {
+                    const double c = area(unite(box[k], box[i]));
+                    if (c < cost[k]) { cost[k] = c; best[k] = i; }
+                }
+            }
+        }
+        return code[0];
+    }
+    // top-down: cut ids[begin, end) where the surface-area heuristic (16 bins along the axis the centres spread most on)
+    // is smallest, until the parts are small enough to be joined bottom-up
+    int split(std::vector<int>& ids, int begin, int end) {
+        const int n = end - begin;
+        if (n <= JOIN_MAX) {
+            std::vector<int> code((size_t)n);
+            for (int k = 0; k < n; k++) code[k] = ~ids[(size_t)begin + k];
+            return agglomerate(std::move(code));
+        }
+        auto centre = [&](int g, int c) { const Box3& b = s.objs[groups[(size_t)g]].box; return (double)b.mn[c] + (double)b.mx[c]; };
+        double lo[3], hi[3];
+        for (int c = 0; c < 3; c++) { lo[c] = hi[c] = centre(ids[begin], c); }
+        for (int k = begin; k < end; k++)
+            for (int c = 0; c < 3; c++) { const double v = centre(ids[k], c); lo[c] = std::min(lo[c], v); hi[c] = std::max(hi[c], v); }
+        int axis = 0;
+        for (int c = 1; c < 3; c++) if (hi[c] - lo[c] > hi[axis] - lo[axis]) axis = c;
+        int mid = begin + n / 2;
+        const double extent = hi[axis] - lo[axis];
+        bool cut = false;
+        if (extent > 0) {
+            constexpr int BINS = 16;
+            Box3 bb[BINS];
+            int cnt[BINS] = {0};
+            auto bin_of = [&](int g) { const int b = (int)((centre(g, axis) - lo[axis]) / extent * BINS); return b < 0 ? 0 : (b >= BINS ? BINS - 1 : b); };
+            for (int k = begin; k < end; k++) {
+                const int b = bin_of(ids[k]);
+                const Box3& gb = s.objs[groups[(size_t)ids[k]]].box;
+                bb[b] = cnt[b] ? unite(bb[b], gb) : gb;
+                cnt[b]++;
+            }
+            double right_area[BINS];
+            int right_cnt[BINS];
+            Box3 acc{};
+            int c_acc = 0;
+            for (int b = BINS - 1; b > 0; b--) {
+                if (cnt[b]) { acc = c_acc ? unite(acc, bb[b]) : bb[b]; c_acc += cnt[b]; }
+                right_area[b] = c_acc ? area(acc) : 0.0;
+                right_cnt[b] = c_acc;
+            }
+            double best_cost = std::numeric_limits<double>::infinity();
+            int best_b = -1;
+            c_acc = 0;
+            for (int b = 1; b < BINS; b++) {          // cut between bin b - 1 and bin b
+                if (cnt[b - 1]) { acc = c_acc ? unite(acc, bb[b - 1]) : bb[b - 1]; c_acc += cnt[b - 1]; }
+                if (c_acc == 0 || right_cnt[b] == 0) continue;
+                const double c = area(acc) * c_acc + right_area[b] * right_cnt[b];
+                if (c < best_cost) { best_cost = c; best_b = b; }
+            }
+            if (best_b > 0) {
+                auto it = std::stable_partition(ids.begin() + begin, ids.begin() + end, [&](int g) { return bin_of(g) < best_b; });
+                mid = (int)(it - ids.begin());
+                cut = mid > begin && mid < end;
+            }
+        }
+        if (!cut) {   // all centres in one place: halves by their place in the reference's order
+            mid = begin + n / 2;
+        }
+        const int a = split(ids, begin, mid), b = split(ids, mid, end);
+        return join(a, b);
+    }
+    bool build(int tree_root) {
+        groups.clear(); nodes.clear();
+        if (const char* v = getenv("RT_JOIN_MAX")) JOIN_MAX = std::max(1, atoi(v));
+        if (!collect(tree_root) || groups.size() < 4) return false;
+        std::vector<int> ids(groups.size());
+        for (size_t k = 0; k < ids.size(); k++) ids[k] = (int)k;
+        nodes.reserve(groups.size());
+        root = split(ids, 0, (int)ids.size());
+        return true;
+    }
+};
+
 // ------------------------------------------------------------------------------------------------- flattening
 struct Flattener {
     const rt_scene& s;
-    rt_scene_flat& f;
-    int first_leaf = -1;   // first leaf entry of the list being emitted
+    rt_layout& f;
+    std::vector<F4>& tris;          // the scene's triangle records, shared by its layouts
+    std::vector<int>& tri_of;       // by object index: the triangle's record, -1 until it has one
+    std::vector<int>& ent_obj;      // by entry of this layout: the object of a leaf or instance entry, -1 for other entries
+    bool regroup = false;           // rebuild the upper levels of the trees that allow it
+    int regrouped_trees = 0, regrouped_groups = 0;
+    int first_leaf = -1;            // first leaf entry of the list being emitted
 
+    void push(const F4& lo, const F4& hi, int obj) {
+        f.ent_lo.push_back(lo);
+        f.ent_hi.push_back(hi);
+        ent_obj.push_back(obj);
+    }
     int emit_leaf(int idx, bool top_level) {
         const Obj& o = s.objs[idx];
         const int at = (int)f.ent_lo.size();
         if (first_leaf < 0) first_leaf = at;
         switch (o.kind) {
         case SPHERE:
-            f.ent_lo.push_back({o.c.x, o.c.y, o.c.z, o.r});
-            f.ent_hi.push_back({bits_f(o.id), 0, 0, bits_f(ENT_SPHERE)});
+            push({o.c.x, o.c.y, o.c.z, o.r}, {bits_f(o.id), 0, 0, bits_f(ENT_SPHERE)}, idx);
             break;
         case CUBE:
-            f.ent_lo.push_back({o.box.mn.x, o.box.mn.y, o.box.mn.z, bits_f(o.id)});
-            f.ent_hi.push_back({o.box.mx.x, o.box.mx.y, o.box.mx.z, bits_f(ENT_CUBE)});
+            push({o.box.mn.x, o.box.mn.y, o.box.mn.z, bits_f(o.id)}, {o.box.mx.x, o.box.mx.y, o.box.mx.z, bits_f(ENT_CUBE)}, idx);
             break;
         case FOG:    // the boundary cube; the density sits in the object table
-            f.ent_lo.push_back({o.box.mn.x, o.box.mn.y, o.box.mn.z, bits_f(o.id)});
-            f.ent_hi.push_back({o.box.mx.x, o.box.mx.y, o.box.mx.z, bits_f(ENT_FOG)});
+            push({o.box.mn.x, o.box.mn.y, o.box.mn.z, bits_f(o.id)}, {o.box.mx.x, o.box.mx.y, o.box.mx.z, bits_f(ENT_FOG)}, idx);
             break;
         case TRI: {
-            const int ti = (int)f.tris.size() / RT_TRI_F4;
-            f.tris.push_back({o.p[0].x, o.p[0].y, o.p[0].z, 0});
-            f.tris.push_back({o.p[1].x, o.p[1].y, o.p[1].z, 0});
-            f.tris.push_back({o.p[2].x, o.p[2].y, o.p[2].z, 0});
-            f.tris.push_back({o.tc[0].x, o.tc[0].y, o.tc[1].x, o.tc[1].y});
-            f.tris.push_back({o.tc[2].x, o.tc[2].y, o.n[0].x, o.n[0].y});
-            f.tris.push_back({o.n[0].z, 0, 0, 0});
-            f.ent_lo.push_back({bits_f(ti), 0, 0, 0});
-            f.ent_hi.push_back({0, 0, 0, bits_f(ENT_TRI)});
+            if (tri_of[(size_t)idx] < 0) {
+                tri_of[(size_t)idx] = (int)tris.size() / RT_TRI_F4;
+                tris.push_back({o.p[0].x, o.p[0].y, o.p[0].z, 0});
+                tris.push_back({o.p[1].x, o.p[1].y, o.p[1].z, 0});
+                tris.push_back({o.p[2].x, o.p[2].y, o.p[2].z, 0});
+                tris.push_back({o.tc[0].x, o.tc[0].y, o.tc[1].x, o.tc[1].y});
+                tris.push_back({o.tc[2].x, o.tc[2].y, o.n[0].x, o.n[0].y});
+                tris.push_back({o.n[0].z, 0, 0, 0});
+            }
+            push({bits_f(tri_of[(size_t)idx]), 0, 0, 0}, {0, 0, 0, bits_f(ENT_TRI)}, idx);
             break;
         }
         default: {   // a MOVE / ROT chain over a mesh or a fog volume = one instance
             (void)top_level;
-            f.ent_lo.push_back({bits_f((int)pending.size()), 0, 0, 0});
-            f.ent_hi.push_back({0, 0, 0, bits_f(ENT_INSTANCE)});
+            push({bits_f((int)pending.size()), 0, 0, 0}, {0, 0, 0, bits_f(ENT_INSTANCE)}, idx);   // (the chain's first object stands for the instance)
             pending.push_back(idx);
             break;
         }
         }
         return at;
     }
+    void note_children(int at, int right_at, int axis) {
+        f.ent_lo[(size_t)at].w = bits_f((int)f.ent_lo.size());
+        f.ent_right.resize(f.ent_lo.size(), -1);
+        f.ent_axis.resize(f.ent_lo.size(), 3);
+        f.ent_right[(size_t)at] = right_at;
+        f.ent_axis[(size_t)at] = (uint8_t)(right_at >= 0 ? (axis >= 0 && axis <= 2 ? axis : 0) : 3);
+    }
     void emit(int idx, bool top_level) {
         const Obj& o = s.objs[idx];
         if (o.kind != NODE) { emit_leaf(idx, top_level); return; }
         const int at = (int)f.ent_lo.size();
-        f.ent_lo.push_back({o.box.mn.x, o.box.mn.y, o.box.mn.z, 0});
-        f.ent_hi.push_back({o.box.mx.x, o.box.mx.y, o.box.mx.z, bits_f(ENT_INNER)});
+        push({o.box.mn.x, o.box.mn.y, o.box.mn.z, 0}, {o.box.mx.x, o.box.mx.y, o.box.mx.z, bits_f(ENT_INNER)}, -1);
         emit(o.left, top_level);
         // a node over a single object has it as both children (Object.cpp:198-200) and tests it twice; for a fog volume
         // the second test draws a new random number and can hit where the first did not, so it is listed twice
         int right_at = -1;
         if (o.right != o.left || draws_random(o.left)) { right_at = (int)f.ent_lo.size(); emit(o.right, top_level); }
-        f.ent_lo[at].w = bits_f((int)f.ent_lo.size());
-        f.ent_right.resize(f.ent_lo.size(), -1);
-        f.ent_axis.resize(f.ent_lo.size(), 3);
-        f.ent_right[at] = right_at;
-        f.ent_axis[at] = (uint8_t)(right_at >= 0 ? (o.axis >= 0 && o.axis <= 2 ? o.axis : 0) : 3);
+        note_children(at, right_at, o.axis);
+    }
+    // a node of a regrouped hierarchy: its box, then the child whose box begins first along the axis on which the two
+    // children's centres lie furthest apart (what the ordered traversal takes for the near child), then the other
+    void emit_regrouped(const Regroup& rg, int child, bool top_level) {
+        if (child < 0) { emit(rg.groups[(size_t)~child], top_level); return; }
+        const Regroup::FNode& n = rg.nodes[(size_t)child];
+        const Box3 &ba = rg.box_of_child(n.a), &bb = rg.box_of_child(n.b);
+        int axis = 0;
+        double far = -1;
+        for (int c = 0; c < 3; c++) {
+            const double d = std::fabs(((double)ba.mn[c] + ba.mx[c]) - ((double)bb.mn[c] + bb.mx[c]));
+            if (d > far) { far = d; axis = c; }
+        }
+        const bool a_first = ba.mn[axis] <= bb.mn[axis];
+        const int at = (int)f.ent_lo.size();
+        push({n.box.mn.x, n.box.mn.y, n.box.mn.z, 0}, {n.box.mx.x, n.box.mx.y, n.box.mx.z, bits_f(ENT_INNER)}, -1);
+        emit_regrouped(rg, a_first ? n.a : n.b, top_level);
+        const int right_at = (int)f.ent_lo.size();
+        emit_regrouped(rg, a_first ? n.b : n.a, top_level);
+        note_children(at, right_at, axis);
+    }
+    // One tree of the scene: the top-level tree or a mesh's.  Only meshes are regrouped.  The top-level tree of a large
+    // scene is walked near side first with distance culling, and there the reference's own upper levels do better than
+    // rebuilt ones: its lowest nodes are the cells of its own partition of space, which no box of its upper levels cuts
+    // through, while any other partition cuts through some of them and gets overlapping boxes for it (measured on the
+    // 100 000-primitive scene: 79 slab tests per ray in the reference's hierarchy, 92 to 100 in rebuilt ones).  A mesh is
+    // never culled (no distance bound exists for a triangle) and its tree of random axes (Object.cpp:191) over thin,
+    // slanted triangles leaves much to gain.
+    void emit_tree(int root, bool top_level) {
+        if (regroup && (!top_level || getenv("RT_REGROUP_TOP"))) {
+            Regroup rg{s};
+            if (rg.build(root)) {
+                regrouped_trees++;
+                regrouped_groups += (int)rg.groups.size();
+                emit_regrouped(rg, rg.root, top_level);
+                return;
+            }
+        }
+        emit(root, top_level);
     }
     bool draws_random(int idx) const {
         while (s.objs[idx].kind == MOVE || s.objs[idx].kind == ROT) idx = s.objs[idx].target;
@@ -301,16 +515,21 @@ struct Flattener {
     std::vector<int> pending;   // instance leaves of the top level, in instance-index order
 };
 
-void flatten(rt_scene& s) {
-    rt_scene_flat& f = s.flat;
-    f = rt_scene_flat();
-    Flattener fl{s, f};
-    fl.emit(s.root, true);
+// One layout of the scene: entries, instance records, what the ordered traversal and distance culling need per entry.
+// inst_obj: by instance of this layout, the object (wrapper chain) it stands for.
+void flatten_layout(const rt_scene& s, rt_layout& f, std::vector<F4>& tris, std::vector<int>& tri_of, std::vector<int>& ent_obj,
+                    std::vector<int>& inst_obj, bool regroup, int* regrouped_trees, int* regrouped_groups) {
+    f = rt_layout();
+    ent_obj.clear();
+    Flattener fl{s, f, tris, tri_of, ent_obj};
+    fl.regroup = regroup;
+    fl.emit_tree(s.root, true);
     f.top_end = (int)f.ent_lo.size();
-    f.ent_lo.push_back({0, 0, 0, 0});
-    f.ent_hi.push_back({0, 0, 0, bits_f(ENT_END)});
+    fl.push({0, 0, 0, 0}, {0, 0, 0, bits_f(ENT_END)}, -1);
     f.stale_entry = fl.first_leaf;
     f.inst.resize(fl.pending.size() * RT_INST_F4);
+    inst_obj = fl.pending;
+    int trees = fl.regrouped_trees, groups = fl.regrouped_groups;
     for (size_t k = 0; k < fl.pending.size(); k++) {
         int idx = fl.pending[k];
         Vec3 offset{0, 0, 0}, pivot{0, 0, 0};
@@ -323,22 +542,26 @@ void flatten(rt_scene& s) {
             idx = s.objs[idx].target;
         }
         const int begin = (int)f.ent_lo.size();
-        Flattener sub{s, f};
-        if (s.objs[idx].kind == MESH) sub.emit(s.objs[idx].root, false);
+        Flattener sub{s, f, tris, tri_of, ent_obj};
+        sub.regroup = regroup;
+        if (s.objs[idx].kind == MESH) sub.emit_tree(s.objs[idx].root, false);
         else sub.emit_leaf(idx, false);   // a wrapped fog volume: a range of one entry
+        trees += sub.regrouped_trees; groups += sub.regrouped_groups;
         const int end = (int)f.ent_lo.size();
-        f.ent_lo.push_back({0, 0, 0, 0});
-        f.ent_hi.push_back({0, 0, 0, bits_f(ENT_END)});
+        sub.push({0, 0, 0, 0}, {0, 0, 0, bits_f(ENT_END)}, -1);
         f.inst[k * RT_INST_F4 + 0] = {offset.x, offset.y, offset.z, has_move};
         f.inst[k * RT_INST_F4 + 1] = {pivot.x, pivot.y, pivot.z, bits_f(axis)};
         f.inst[k * RT_INST_F4 + 2] = {sin_t, cos_t, bits_f(begin), bits_f(end)};
         f.inst[k * RT_INST_F4 + 3] = {bits_f(id), bits_f(sub.first_leaf), 0, 0};
     }
+    if (regrouped_trees) *regrouped_trees = trees;
+    if (regrouped_groups) *regrouped_groups = groups;
     f.idle_entry = (int)f.ent_lo.size();
-    f.ent_lo.push_back({0, 0, 0, 0});
-    f.ent_hi.push_back({0, 0, 0, bits_f(ENT_IDLE)});
+    fl.push({0, 0, 0, 0}, {0, 0, 0, bits_f(ENT_IDLE)}, -1);
     f.ent_right.resize(f.ent_lo.size(), -1);
     f.ent_axis.resize(f.ent_lo.size(), 3);
+    f.ent_peer.assign(f.ent_lo.size(), -1);
+    f.ent_rank.assign(f.ent_lo.size(), 0u);
     // Ordered traversal (rt_device.h, "ordered traversal") keeps the children it has yet to visit on a per-ray stack: an
     // inner entry with two children adds one while its first child's subtree is walked, a mesh instance one (the way
     // back out) while its own tree is walked; one more slot holds the end of the top-level list.  Children follow their
@@ -357,47 +580,96 @@ void flatten(rt_scene& s) {
         }
         f.stack_need = 1 + need[0];
     }
+    // Distance culling data (see rt_device.h).  Entries are in preorder and an inner entry's skip index is the end of its
+    // subtree, so walking the indices downwards meets the children of an entry before the entry itself.
+    {
+        const float INF = std::numeric_limits<float>::infinity();
+        const size_t n = f.ent_lo.size();
+        f.ent_rho.assign(n, INF);
+        for (int i = f.top_end - 1; i >= 0; i--) {
+            const int kind = bits_i(f.ent_hi[i].w);
+            if (kind == ENT_SPHERE) {
+                const float r = f.ent_lo[i].w;
+                const float cm = std::fmax(std::fabs(f.ent_lo[i].x), std::fmax(std::fabs(f.ent_lo[i].y), std::fabs(f.ent_lo[i].z)));
+                if (r > 0 && r <= FLT_MAX && cm <= FLT_MAX) f.ent_rho[i] = (0.5f / r) * 1.000001f;
+            } else if (kind == ENT_CUBE) {
+                const bool ordered = f.ent_lo[i].x <= f.ent_hi[i].x && f.ent_lo[i].y <= f.ent_hi[i].y && f.ent_lo[i].z <= f.ent_hi[i].z;
+                if (ordered) f.ent_rho[i] = 0.0f;
+            } else if (kind == ENT_INNER) {
+                const int skip = bits_i(f.ent_lo[i].w);
+                float rho = 0.0f;
+                for (int c = i + 1; c < skip; c = bits_i(f.ent_hi[c].w) == ENT_INNER ? bits_i(f.ent_lo[c].w) : c + 1) rho = std::fmax(rho, f.ent_rho[c]);
+                const bool ordered = f.ent_lo[i].x <= f.ent_hi[i].x && f.ent_lo[i].y <= f.ent_hi[i].y && f.ent_lo[i].z <= f.ent_hi[i].z;
+                f.ent_rho[i] = ordered ? rho : INF;
+            }
+        }
+    }
+}
+
+void flatten(rt_scene& s) {
+    rt_scene_flat& f = s.flat;
+    f = rt_scene_flat();
+    std::vector<int> tri_of(s.objs.size(), -1), ent_obj, inst_obj;
+    flatten_layout(s, f, f.tris, tri_of, ent_obj, inst_obj, false, nullptr, nullptr);
+    // every leaf's place in the order in which the reference meets the leaves: the top-level list from its start, a
+    // mesh's triangles where its instance's entry stands
+    {
+        uint32_t rank = 0;
+        auto is_leaf = [&](int i) { const int k = bits_i(f.ent_hi[i].w); return k >= ENT_SPHERE && k <= ENT_FOG; };
+        for (int i = 0; i < f.top_end; i++) {
+            if (is_leaf(i)) f.ent_rank[i] = rank++;
+            else if (bits_i(f.ent_hi[i].w) == ENT_INSTANCE) {
+                const size_t k = (size_t)bits_i(f.ent_lo[i].x) * RT_INST_F4;
+                for (int j = bits_i(f.inst[k + 2].z); j < bits_i(f.inst[k + 2].w); j++)
+                    if (is_leaf(j)) f.ent_rank[j] = rank++;
+            }
+        }
+    }
     f.fast_div_ok = true;
+    bool has_fog = false;
+    float r_max = 0, c_max = 0;
     for (size_t i = 0; i < f.ent_lo.size(); i++) {
-        if (bits_i(f.ent_hi[i].w) != ENT_INNER) continue;
+        const int kind = bits_i(f.ent_hi[i].w);
+        if (kind == ENT_FOG) has_fog = true;
+        if (kind == ENT_SPHERE && i < (size_t)f.top_end) {
+            const float r = f.ent_lo[i].w;
+            const float cm = std::fmax(std::fabs(f.ent_lo[i].x), std::fmax(std::fabs(f.ent_lo[i].y), std::fabs(f.ent_lo[i].z)));
+            if (r > 0 && r <= FLT_MAX && cm <= FLT_MAX) { r_max = std::fmax(r_max, r); c_max = std::fmax(c_max, cm + r); }
+        }
+        if (kind != ENT_INNER) continue;
         const float c[6] = {f.ent_lo[i].x, f.ent_lo[i].y, f.ent_lo[i].z, f.ent_hi[i].x, f.ent_hi[i].y, f.ent_hi[i].z};
         for (float v : c) {
             const float a = std::fabs(v);
             if (!(v == 0.0f || (a >= 8.8817841970012523e-16f && a <= 1.099511627776e12f))) f.fast_div_ok = false;
         }
     }
-    // Distance culling data (see rt_device.h).  Entries are in preorder and an inner entry's skip index is the end of its
-    // subtree, so walking the indices downwards meets both children of an entry before the entry itself.
-    {
-        const float INF = std::numeric_limits<float>::infinity();
-        const size_t n = f.ent_lo.size();
-        f.ent_rho.assign(n, INF);
-        float r_max = 0, c_max = 0;
-        for (int i = f.top_end - 1; i >= 0; i--) {
-            const int kind = bits_i(f.ent_hi[i].w);
-            if (kind == ENT_SPHERE) {
-                const float r = f.ent_lo[i].w;
-                const float cm = std::fmax(std::fabs(f.ent_lo[i].x), std::fmax(std::fabs(f.ent_lo[i].y), std::fabs(f.ent_lo[i].z)));
-                if (r > 0 && r <= FLT_MAX && cm <= FLT_MAX) {
-                    f.ent_rho[i] = (0.5f / r) * 1.000001f;
-                    r_max = std::fmax(r_max, r);
-                    c_max = std::fmax(c_max, cm + r);
-                }
-            } else if (kind == ENT_CUBE) {
-                const bool ordered = f.ent_lo[i].x <= f.ent_hi[i].x && f.ent_lo[i].y <= f.ent_hi[i].y && f.ent_lo[i].z <= f.ent_hi[i].z;
-                if (ordered) f.ent_rho[i] = 0.0f;
-            } else if (kind == ENT_INNER) {
-                const int skip = bits_i(f.ent_lo[i].w), c1 = i + 1;
-                const int c2 = bits_i(f.ent_hi[c1].w) == ENT_INNER ? bits_i(f.ent_lo[c1].w) : c1 + 1;
-                float rho = f.ent_rho[c1];
-                if (c2 < skip) rho = std::fmax(rho, f.ent_rho[c2]);      // a node over one object lists it once
-                const bool ordered = f.ent_lo[i].x <= f.ent_hi[i].x && f.ent_lo[i].y <= f.ent_hi[i].y && f.ent_lo[i].z <= f.ent_hi[i].z;
-                f.ent_rho[i] = ordered ? rho : INF;
+    f.cull_2rmax = 2.0f * r_max;
+    f.cull_cabs = r_max * 1.52587890625e-05f;                                    // 2^-16 r_max
+    f.cull_delta = (c_max + 2.0f * r_max) * 1.1920928955078125e-07f;             // 2^-23 (max |c| + r) + 2^-22 r_max
+    // The regrouped layout (see "regrouping"); never with fog, whose random draws follow the reference's visiting order
+    if (f.fast_div_ok && !has_fog && !getenv("RT_NO_REGROUP")) {
+        std::vector<int> ent_obj_fast, inst_obj_fast;
+        flatten_layout(s, f.fast, f.tris, tri_of, ent_obj_fast, inst_obj_fast, true, &f.regrouped_trees, &f.regrouped_groups);
+        if (f.regrouped_trees > 0) {
+            f.has_fast = true;
+            std::vector<int> at_fast(s.objs.size(), -1);
+            for (size_t e = 0; e < ent_obj_fast.size(); e++) if (ent_obj_fast[e] >= 0) at_fast[(size_t)ent_obj_fast[e]] = (int)e;
+            for (size_t e = 0; e < ent_obj.size(); e++) {
+                if (ent_obj[e] < 0) continue;
+                const int fe = at_fast[(size_t)ent_obj[e]];
+                f.ent_peer[e] = fe;
+                f.fast.ent_peer[(size_t)fe] = (int)e;
+                f.fast.ent_rank[(size_t)fe] = f.ent_rank[e];
             }
-        }
-        f.cull_2rmax = 2.0f * r_max;
-        f.cull_cabs = r_max * 1.52587890625e-05f;                                    // 2^-16 r_max
-        f.cull_delta = (c_max + 2.0f * r_max) * 1.1920928955078125e-07f;             // 2^-23 (max |c| + r) + 2^-22 r_max
+            // the leaves whose rejected HitInfo.distance survives are the reference's first leaves, wherever they stand now
+            f.fast.stale_entry = f.stale_entry >= 0 ? f.ent_peer[(size_t)f.stale_entry] : -1;
+            for (size_t kf = 0; kf < inst_obj_fast.size(); kf++)
+                for (size_t kr = 0; kr < inst_obj.size(); kr++)
+                    if (inst_obj[kr] == inst_obj_fast[kf]) {
+                        const int first = bits_i(f.inst[kr * RT_INST_F4 + 3].y);
+                        f.fast.inst[kf * RT_INST_F4 + 3].y = bits_f(first >= 0 ? f.ent_peer[(size_t)first] : -1);
+                    }
+        } else f.fast = rt_layout();
     }
     // texel pool: images, then the skybox; each padded by one zero row because uv == 1.0 indexes row h
     // (Object.cpp:546-547 wrap; World.cpp:174-183 has no clamp)
@@ -816,6 +1088,61 @@ int rt_scene_flat_info(const rt_scene* s, int64_t out[7]) {
     out[4] = (int64_t)f.planes.size();
     out[5] = (int64_t)f.texels.size();
     out[6] = (int64_t)(16 * (f.ent_lo.size() * 2 + f.tris.size() + f.inst.size() + f.objects.size() + f.planes.size()) + f.texels.size());
+    return RT_OK;
+}
+
+// Expected number of slab tests for a random line through the root box of the tree in entries [begin, end) of a layout
+// (surface-area measure: a node's box is tested when its parent's box is hit).
+static double expected_box_tests(const rt_layout& L, int begin, int end) {
+    auto area = [&](int i) {
+        const double x = (double)L.ent_hi[i].x - L.ent_lo[i].x, y = (double)L.ent_hi[i].y - L.ent_lo[i].y, z = (double)L.ent_hi[i].z - L.ent_lo[i].z;
+        return x * y + y * z + x * z;
+    };
+    if (begin >= end || bits_i(L.ent_hi[begin].w) != ENT_INNER) return 0.0;
+    const double root = area(begin);
+    if (!(root > 0)) return 0.0;
+    double sum = 1.0;
+    for (int i = begin; i < end; i++) {
+        if (bits_i(L.ent_hi[i].w) != ENT_INNER) continue;
+        const int skip = bits_i(L.ent_lo[i].w);
+        int inner_children = 0;
+        for (int c = i + 1; c < skip; c = bits_i(L.ent_hi[c].w) == ENT_INNER ? bits_i(L.ent_lo[c].w) : c + 1)
+            if (bits_i(L.ent_hi[c].w) == ENT_INNER) inner_children++;
+        sum += inner_children * area(i) / root;
+    }
+    return sum;
+}
+// The entries of a layout as the host holds them (rt_flat.h): per entry lo.xyzw, hi.xyzw, then the peer entry in the other
+// layout and the rank of a leaf.  Returns the number of entries (the arrays may be null to ask for it), or an error.
+int rt_scene_dump_entries(const rt_scene* s, int regrouped, int max_entries, float* lo_hi8, int32_t* peer, uint32_t* rank) {
+    if (!s || !s->built) return fail(RT_E_INVALID, "scene is not built");
+    const rt_scene_flat& f = s->flat;
+    if (regrouped && !f.has_fast) return fail(RT_E_INVALID, "the scene has no regrouped layout");
+    const rt_layout& L = regrouped ? f.fast : static_cast<const rt_layout&>(f);
+    const int n = (int)L.ent_lo.size();
+    if (!lo_hi8 && !peer && !rank) return n;
+    if (n > max_entries) return fail(RT_E_INVALID, "entry buffer too small");
+    for (int i = 0; i < n; i++) {
+        if (lo_hi8) { memcpy(lo_hi8 + 8 * (size_t)i, &L.ent_lo[i], 16); memcpy(lo_hi8 + 8 * (size_t)i + 4, &L.ent_hi[i], 16); }
+        if (peer) peer[i] = L.ent_peer[i];
+        if (rank) rank[i] = L.ent_rank[i];
+    }
+    return n;
+}
+int rt_scene_regroup_info(const rt_scene* s, double out[8]) {
+    if (!s || !s->built || !out) return fail(RT_E_INVALID, "scene is not built");
+    const rt_scene_flat& f = s->flat;
+    for (int k = 0; k < 8; k++) out[k] = 0;
+    out[0] = f.has_fast ? 1 : 0;
+    out[1] = f.regrouped_trees;
+    out[2] = f.regrouped_groups;
+    out[3] = expected_box_tests(f, 0, f.top_end);
+    for (size_t k = 0; k + RT_INST_F4 <= f.inst.size(); k += RT_INST_F4) out[4] += expected_box_tests(f, bits_i(f.inst[k + 2].z), bits_i(f.inst[k + 2].w));
+    if (f.has_fast) {
+        out[5] = expected_box_tests(f.fast, 0, f.fast.top_end);
+        for (size_t k = 0; k + RT_INST_F4 <= f.fast.inst.size(); k += RT_INST_F4) out[6] += expected_box_tests(f.fast, bits_i(f.fast.inst[k + 2].z), bits_i(f.fast.inst[k + 2].w));
+        out[7] = f.fast.stack_need;
+    }
     return RT_OK;
 }
 

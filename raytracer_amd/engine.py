@@ -19,6 +19,7 @@ TRACE_STATIC_MAX_RAYS = 32768   # RT_TRACE_STATIC_MAX_RAYS
 FLAG_NO_CULL = 1                # RT_FLAG_NO_CULL
 FLAG_NO_LDS = 2                 # RT_FLAG_NO_LDS
 FLAG_NO_ORDER = 4               # RT_FLAG_NO_ORDER
+FLAG_NO_REGROUP = 8             # RT_FLAG_NO_REGROUP
 
 f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
@@ -75,6 +76,8 @@ SIGNATURES = {
     "rt_scene_dump_objects": (C.c_int, [_V, C.c_int, f32p]),
     "rt_scene_dump_instance": (C.c_int, [_V, C.c_int, f32p]),
     "rt_scene_flat_info": (C.c_int, [_V, i64p]),
+    "rt_scene_regroup_info": (C.c_int, [_V, f64p]),
+    "rt_scene_dump_entries": (C.c_int, [_V, C.c_int, C.c_int, _V, _V, _V]),
     "rt_load_obj": (C.c_int, [C.c_char_p, C.c_int, _V]),
     "rt_load_png": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int64, _V, i32p, i32p, i32p]),
     "rt_camera_look": (None, [f32p, f32p, f32p]),
@@ -304,6 +307,21 @@ class Scene:
         out = np.zeros(17, np.float32)
         _check(self.L.rt_scene_dump_instance(self.h, oid, out))
         return out
+
+    def dump_entries(self, regrouped=False):
+        """(lo_hi [n, 8] float32, peer [n] int32, rank [n] uint32) of the reference's layout or the regrouped one"""
+        n = _check(self.L.rt_scene_dump_entries(self.h, int(regrouped), 0, None, None, None))
+        e = np.zeros((n, 8), np.float32)
+        peer = np.zeros(n, np.int32)
+        rank = np.zeros(n, np.uint32)
+        _check(self.L.rt_scene_dump_entries(self.h, int(regrouped), n, _ptr(e), _ptr(peer), _ptr(rank)))
+        return e, peer, rank
+
+    def regroup_info(self):
+        out = np.zeros(8, np.float64)
+        _check(self.L.rt_scene_regroup_info(self.h, out))
+        return dict(zip(("has_regrouped_layout", "trees", "lowest_nodes", "top_tests_reference", "mesh_tests_reference", "top_tests_regrouped",
+                         "mesh_tests_regrouped", "stack_slots"), (float(v) for v in out)))
 
     def flat_info(self):
         out = np.zeros(7, np.int64)

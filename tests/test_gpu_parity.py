@@ -618,6 +618,57 @@ def test_fog_scene(rt, orc, golden, assets):
     assert_bits(e2.render_frame(int(g["seed"])), frame, "fog scene, batched")
 
 
+def test_rays_the_regrouped_hierarchy_is_not_proven_for(rt, oracle_default, gpu_default):
+    """The engine walks a hierarchy of its own above the lowest nodes of a mesh's tree; that is exact for every ray whose
+    slab-test quotients are numbers.  Rays with a direction component that is exactly zero (+0 or -0: the reference's
+    test takes -0 for a direction that points the other way) — in the scene's frame, or only in the frame of the tree's
+    rotated instance — are handed over to a walk through the reference's own hierarchy.  Closest hits and radiance of
+    such rays through the tree's mesh, against the oracle and against an engine that walks the reference's hierarchy
+    throughout, bit for bit; and the hand-over really happens."""
+    rng = np.random.default_rng(5)
+    n = 6000
+    # origins around the tree (centre (0,5,0), 10 units high), directions along the axes and in the coordinate planes
+    o = rng.uniform([-6, 0.2, -6], [6, 11, 6], (n, 3)).astype(np.float32)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    zero = rng.integers(0, 3, n)
+    d[np.arange(n), zero] = np.where(rng.random(n) < 0.5, np.float32(0.0), np.float32(-0.0))
+    second = rng.random(n) < 0.4                       # two zero components: axis-parallel rays
+    d[second, (zero[second] + 1) % 3] = np.where(rng.random(second.sum()) < 0.5, np.float32(0.0), np.float32(-0.0))
+    d /= np.sqrt((d.astype(np.float64) ** 2).sum(axis=1, keepdims=True)).astype(np.float32)
+    # aimed at the tree from outside its box
+    o[: n // 2] = (np.array([0, 5, 0], np.float32) - d[: n // 2] * rng.uniform(6, 15, (n // 2, 1)).astype(np.float32)
+                   + rng.uniform(-3, 3, (n // 2, 3)).astype(np.float32) * (d[: n // 2] == 0))
+    # a zero component only after the instance's rotation by 90 degrees about x (sin = 1, cos = -4.37e-8):
+    # d'.y = cos * d.y - sin * d.z is exactly 0 for d.z = cos * d.y
+    m = 500
+    o2 = rng.uniform([-5, 1, -9], [5, 9, -7], (m, 3)).astype(np.float32)
+    dy = rng.uniform(0.2, 1.0, m).astype(np.float32)
+    cos_t = np.float32(np.cos(np.float32(90.0 * 0.01745329251994329576923690768489)))
+    d2 = np.stack([rng.uniform(-0.3, 0.3, m).astype(np.float32), dy, cos_t * dy], axis=1).astype(np.float32)
+    assert np.all(cos_t * d2[:, 1] - np.float32(1.0) * d2[:, 2] == 0)
+    o = np.concatenate([o, o2])
+    d = np.concatenate([d, d2])
+    keys = (np.arange(len(o), dtype=np.uint64) * 2654435761 % (1 << 32)).astype(np.uint32)
+    e = make_engine(rt, gpu_default, 128, 128, 1, 4)
+    e0 = make_engine(rt, gpu_default, 128, 128, 1, 4, flags=rt.engine.FLAG_NO_REGROUP)
+    assert gpu_default.regroup_info()["has_regrouped_layout"] == 1
+    hit, rec = e.trace(o, d)
+    hit0, rec0 = e0.trace(o, d)
+    h_or, r_or = oracle_default.trace(o, d)
+    assert_bits(hit, h_or, "ids of rays with zero direction components vs the oracle")
+    assert_bits(rec[:, 0], r_or[:, 0], "their distances vs the oracle")
+    assert_bits(hit, hit0, "ids vs the engine on the reference's hierarchy")
+    assert_bits(rec, rec0, "hit records vs the engine on the reference's hierarchy")
+    assert (hit == 2).sum() > 300                      # many of them do meet the tree
+    col = e.ray_color(o, d, 4, keys)
+    assert_bits(col, oracle_default.ray_color(o, d, 4, keys), "radiance of such rays vs the oracle")
+    assert_bits(col, e0.ray_color(o, d, 4, keys), "radiance vs the engine on the reference's hierarchy")
+    # a frame through both hierarchies, and the work the regrouped one saves
+    a, a0 = e.render_frame(3), e0.render_frame(3)
+    assert_bits(a, a0, "frame through the regrouped and through the reference's hierarchy")
+    assert e.stats()["box_tests"] < 0.95 * e0.stats()["box_tests"]
+
+
 @pytest.mark.parametrize("case", ["single_sphere_no_plane", "single_fog", "one_pixel", "no_bounces", "max_bounces"])
 def test_degenerate_scenes_and_sizes(rt, orc, assets, case):
     """the small ends of the input space: a BVH whose root has the same object as both children (Object.cpp:198-200), a
@@ -693,7 +744,9 @@ def test_random_scenes_bit_exact(rt, orc, assets, seed, monkeypatch):
     # (scenes without fog read from memory are walked near side first with a stack; FLAG_NO_ORDER selects the
     # reference's order without one, as scenes with fog are always walked)
     E = rt.engine
-    for flags in (E.FLAG_NO_LDS, E.FLAG_NO_LDS | E.FLAG_NO_CULL, E.FLAG_NO_LDS | E.FLAG_NO_ORDER, E.FLAG_NO_LDS | E.FLAG_NO_ORDER | E.FLAG_NO_CULL, 0):
+    # (FLAG_NO_REGROUP: the reference's hierarchy above the lowest nodes of the meshes' trees instead of the engine's own)
+    for flags in (E.FLAG_NO_LDS, E.FLAG_NO_LDS | E.FLAG_NO_CULL, E.FLAG_NO_LDS | E.FLAG_NO_ORDER, E.FLAG_NO_LDS | E.FLAG_NO_ORDER | E.FLAG_NO_CULL, 0,
+                  E.FLAG_NO_REGROUP, E.FLAG_NO_REGROUP | E.FLAG_NO_LDS):
         m = make_engine(rt, scene, W, H, S, B, cam, flags=flags)
         m.keep_samples(True)
         frame_m = m.render_frame(seed)
@@ -815,8 +868,14 @@ def test_distance_culling_changes_nothing(rt, orc, assets):
     n_unordered = e1.stats()["box_tests"]
     assert_bits(a, a0, "frame with and without culling")
     assert_bits(a, a1, "frame near side first and in the reference's order")
-    assert 0 < n_cull < n_unordered < 0.7 * n_all, (n_cull, n_unordered, n_all)
-    print(f"slab tests per frame: {n_all} all, {n_unordered} culled in the reference's order, {n_cull} culled near side first")
+    # ... and through the reference's own hierarchy, every box the reference visits (no regrouped upper levels, no culling)
+    e2 = make_engine(rt, scene, 256, 256, 2, 4, cam, flags=rt.engine.FLAG_NO_CULL | rt.engine.FLAG_NO_REGROUP)
+    assert_bits(e2.ray_color(o, d, 4, keys), col, "radiance through the reference's hierarchy")
+    a2 = e2.render_frame(5)
+    n_ref = e2.stats()["box_tests"]
+    assert_bits(a, a2, "frame through the regrouped and through the reference's hierarchy")
+    assert 0 < n_cull < n_unordered < n_all <= n_ref and n_unordered < 0.7 * n_ref, (n_cull, n_unordered, n_all, n_ref)
+    print(f"slab tests per frame: {n_ref} in the reference's hierarchy, {n_all} regrouped, {n_unordered} culled in the stored child order, {n_cull} culled near side first")
 
 
 @pytest.fixture(scope="module")

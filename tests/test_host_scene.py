@@ -216,3 +216,62 @@ def test_c3_tree_built_by_the_product(rt, golden, assets):
         assert_bits(got[::1000], g[f"top_{name}_rows"], f"C3 tree {name}, every 1000th row")
         assert hashlib.sha256(np.ascontiguousarray(got).tobytes()).digest() == g[f"top_{name}_sha256"].tobytes(), f"C3 tree {name}"
     print(f"C3 scene through the C ABI: {dt:.2f} s including {int(g['n'])} object and material calls from Python")
+
+
+@pytest.mark.parametrize("key", [0x12345678, 0x5EED0001, 7])
+def test_regrouped_layout_keeps_the_lowest_nodes_and_their_leaves(rt, key):
+    """The regrouped layout (the levels of a mesh's tree above its lowest nodes rebuilt): every leaf and every lowest node
+    of the reference's layout is there with the same bits, leaves keep their ranks, every box of the new upper levels
+    contains the boxes below it (which is what makes it visit every lowest node the reference visits), and the top-level
+    tree — whose boxes over negative radii are not even ordered — is left alone."""
+    ENT_INNER, ENT_TRI, ENT_INSTANCE = 0, 3, 8
+    s = rt.default_scene(key)
+    info = s.regroup_info()
+    assert info["has_regrouped_layout"] == 1 and info["trees"] == 1 and info["lowest_nodes"] == 256
+    assert info["mesh_tests_regrouped"] < 0.8 * info["mesh_tests_reference"], info
+    assert info["top_tests_regrouped"] == info["top_tests_reference"]
+    ref, ref_peer, ref_rank = s.dump_entries(False)
+    new, new_peer, new_rank = s.dump_entries(True)
+    assert len(ref) == len(new)                                        # a binary tree over the same lowest nodes
+    kind = lambda e: e[:, 7].view(np.int32)
+    link = lambda e: e[:, 3].view(np.int32)
+    leaf_r = np.nonzero((kind(ref) >= 1) & (kind(ref) <= 4))[0]
+    leaf_n = np.nonzero((kind(new) >= 1) & (kind(new) <= 4))[0]
+    assert len(leaf_r) == len(leaf_n) and (kind(ref) == ENT_TRI).sum() == 457
+    # leaves: same data, same rank, peers point at each other; ranks number the leaves in the reference's order
+    assert sorted(ref_peer[leaf_r].tolist()) == leaf_n.tolist()
+    assert (new_peer[ref_peer[leaf_r]] == leaf_r).all()
+    assert_bits(new[ref_peer[leaf_r]], ref[leaf_r], "leaf entries of the two layouts")
+    assert (new_rank[ref_peer[leaf_r]] == ref_rank[leaf_r]).all()
+    assert sorted(ref_rank[leaf_r].tolist()) == list(range(len(leaf_r)))
+    # lowest nodes (inner entries followed by leaves only): the same boxes, each still followed by its own leaves
+    def lowest(e):
+        out = {}
+        k, ln = kind(e), link(e)
+        for i in np.nonzero(k == ENT_INNER)[0]:
+            kids = list(range(i + 1, ln[i]))
+            if kids and all(1 <= k[c] <= 4 for c in kids):
+                out[i] = kids
+        return out
+    low_r, low_n = lowest(ref), lowest(new)
+    by_leaves = {tuple(ref_peer[c] for c in kids): i for i, kids in low_r.items()}
+    assert len(low_n) == len(low_r)
+    for j, kids in low_n.items():
+        i = by_leaves[tuple(kids)]
+        assert ref[i, [0, 1, 2, 4, 5, 6]].tobytes() == new[j, [0, 1, 2, 4, 5, 6]].tobytes()
+    # containment, in the instance's range of the regrouped layout
+    k, ln = kind(new), link(new)
+    inner = np.nonzero(k == ENT_INNER)[0]
+    top_end = int(np.nonzero(kind(ref) == 5)[0][0])
+    assert_bits(new[:top_end + 1], ref[:top_end + 1], "top-level list")
+    checked = 0
+    for i in inner[inner > top_end]:
+        c = i + 1
+        while c < ln[i]:
+            if k[c] == ENT_INNER:
+                assert (new[i, 0:3] <= new[c, 0:3]).all() and (new[i, 4:7] >= new[c, 4:7]).all(), (i, c)
+                checked += 1
+                c = ln[c]
+            else:
+                c += 1
+    assert checked >= 500
