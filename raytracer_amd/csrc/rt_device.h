@@ -1359,10 +1359,18 @@ __device__ __forceinline__ void sphere_uv(Hit& h) {
     h.u = pm_atan2f(h.normal.x, h.normal.z) / (2 * 3.14159265358979323846264338327950288f) + 0.5f;
     h.v = h.normal.y * 0.5f + 0.5f;
 }
-// Texture::GetColorValue of the three texture classes (DataUtility.h:91, DataUtility.cpp:84-96, 113-121)
-__device__ inline V3 texture_color(const Scene& sc, const float4* ob, Hit& h) {
+// Texture::GetColorValue of the three texture classes (DataUtility.h:91, DataUtility.cpp:84-96, 113-121) — in two steps.
+// The recursion of World::GetRayColor multiplies a bounce's texture colour in on the way BACK (World.cpp:138,151,166), so
+// the colour is needed when the path ends, not when the bounce happens.  A bounce therefore only records WHERE its colour
+// is — four bytes — and the colour is looked up when the path unwinds:
+//   bits 31-30: 0 = the first colour of object `payload` (a plain colour, or the checker's colour for a negative product
+//               of sines), 1 = the object's second colour, 2 = the texel at byte 4 * payload of the texel pool
+//   bit 29:     the bounce halves what comes back (lightDarknerFactor of a diffuse surface, World.cpp:129)
+//   bits 28-0:  payload (object ids stay below 2^28, the texel pool below 2^31 bytes: rt_engine_set_scene checks)
+constexpr uint32_t REF_SECOND = 1u << 30, REF_TEXEL = 2u << 30, REF_HALF = 1u << 29, REF_PAYLOAD = (1u << 29) - 1u;
+__device__ inline uint32_t texture_ref(const Scene& sc, const float4* ob, int object, Hit& h) {
     const int kind = __float_as_int(ob[0].y);
-    if (kind == 0) return xyz(ob[1]);
+    if (kind == 0) return (uint32_t)object;
     if (kind == 1) {
         // the checker only asks whether the product of three sines is negative: with every factor well away from zero
         // that is the parity of their signs; otherwise the product itself is formed
@@ -1372,11 +1380,16 @@ __device__ inline V3 texture_color(const Scene& sc, const float4* ob, Hit& h) {
         bool negative;
         if ((sx | sy | sz) >= 0) negative = ((sx ^ sy ^ sz) & 1) != 0;
         else negative = pm_sinf(ax) * pm_sinf(ay) * pm_sinf(az) < 0.0f;
-        return negative ? xyz(ob[1]) : xyz(ob[2]);
+        return negative ? (uint32_t)object : (REF_SECOND | (uint32_t)object);
     }
     if (h.sphere) sphere_uv(h);
     const rt::ImageRec im = sc.images[__float_as_int(ob[0].z)];
-    return texel_color(sc.texels + im.offset + (uint32_t)image_index(im, h.u, h.v));
+    return REF_TEXEL | ((im.offset + (uint32_t)image_index(im, h.u, h.v)) >> 2);   // (image offsets are multiples of 16)
+}
+__device__ inline V3 ref_color(const Scene& sc, uint32_t ref) {
+    if (ref & REF_TEXEL) return texel_color(sc.texels + 4u * (size_t)(ref & REF_PAYLOAD));
+    const float4* ob = sc.objects + (size_t)(ref & REF_PAYLOAD) * rt::RT_OBJ_F4;
+    return xyz((ref & REF_SECOND) ? ob[2] : ob[1]);
 }
 
 }  // namespace rtd

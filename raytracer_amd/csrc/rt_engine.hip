@@ -16,7 +16,8 @@
 // as coherent as primary rays get (enumerating the paths sample-major instead costs the first intersect pass 20 %).
 // Its RNG stream is keyed by (frame seed, pixel, sample), so the result of a slot does not depend on scheduling.  The
 // recursion of World::GetRayColor multiplies colours on the way back (innermost first); to reproduce that rounding order
-// every bounce stores its (factor, texture colour) in a per-slot stack which the terminating pass unwinds.
+// every bounce records where its texture colour is (four bytes: with the ray for the latest bounce, in a per-slot row for
+// the ones before) and the terminating pass looks the colours up and multiplies them in, innermost first.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -129,7 +130,9 @@ struct Queues {
     uint32_t* exc;                   // queue positions of the rays of the running pass that were handed over (regrouped layouts)
     uint32_t* counts;                // counts[k] = rays entering pass k
     uint32_t* cursors;               // cursors[r * CUR_STRIDE + k] = positions of range r of pass k handed out to intersect waves so far
-    float4* stack;                   // [depth][slot] = (texture colour rgb, factor)
+    uint32_t* c[2];                  // by queue position, beside the ray records: where the colour of the path's latest bounce is (texture_ref)
+    uint32_t* stack;                 // [slot][depth]: the same for the bounces before the latest (paths of two bounces and more)
+    int stack_depth;                 // depths per slot (the engine's bounce count)
     float4* radiance;                // [slot] = sample radiance
     int capacity;                    // slots
 };
@@ -463,9 +466,15 @@ __global__ __launch_bounds__(256) void exceptions_kernel(Scene sc_ref, Cam cam, 
 // ---- one bounce of World::GetRayColor (World.cpp:121-170) for a ray whose closest hit is known.  Returns true when the
 // path goes on: `next` is the bounce ray, the (factor, texture colour) of this bounce is on the path's colour stack.
 // Otherwise the path ends here: the stack is unwound and the sample's radiance stored.
+// The colours the recursion multiplies in on the way back are looked up when the path ends (rt_device.h, texture_ref): a
+// bounce records four bytes.  The latest bounce's travel with the ray (`carried`, beside its queue record: read and
+// written in queue order); when the path bounces again they move to the path's own row stack[slot][depth - 1].  Four
+// paths in five end with one bounce behind them and never touch that row; the others read it once, one 32-byte sector
+// for up to eight bounces.  (Records of (colour, factor) by [depth][slot], as before, were 16 bytes written at every
+// bounce and one scattered 16-byte read per depth at the end: a third of the shading kernels' memory traffic.)
 template <bool FIRST>
 __device__ __forceinline__ bool shade_ray(const Scene& sc, const Cfg& g, const Batch& bt, const Queues& q, const Debug& dbg, const Ray& ray, Rng& rng,
-                                          uint32_t slot, uint32_t depth, const Closest& c, Ray& next) {
+                                          uint32_t slot, uint32_t depth, const Closest& c, uint32_t carried, Ray& next, uint32_t& next_ref) {
     bool alive = false;
     Hit h;
     if (c.hit) finalize_hit(sc, ray, c, h);
@@ -481,25 +490,29 @@ __device__ __forceinline__ bool shade_ray(const Scene& sc, const Cfg& g, const B
         const int remaining = g.B - (int)depth;       // the recursion's bounceAmount
         if (mtype == RT_MAT_LIGHT) L = xyz(ob[3]);
         else if (mtype != RT_MAT_NONE && remaining != 0) {
-            float factor = 1.0f;
             next.o = h.point;
             if (!FIRST && mtype != RT_MAT_METAL) rng.key = slot_key(g, bt, dbg, slot);   // the bounce draws: now the stream is needed
+            uint32_t half = 0u;
             if (mtype == RT_MAT_DIFFUSE) {
                 next.d = normalize(h.normal + unit_sphere_point(rng));
-                factor = 0.5f;                        // lightDarknerFactor (World.cpp:129)
+                half = REF_HALF;                      // lightDarknerFactor (World.cpp:129)
             } else if (mtype == RT_MAT_METAL) {
                 next.d = normalize(ray.d - (h.normal * 2.0f) * dot(ray.d, h.normal));
             } else next.d = unit_sphere_point(rng);    // Isotropic (World.cpp:163)
-            const V3 tex = texture_color(sc, ob, h);
-            q.stack[(size_t)depth * q.capacity + slot] = make_float4(tex.x, tex.y, tex.z, factor);
+            next_ref = texture_ref(sc, ob, h.object, h) | half;
+            if (!FIRST && depth != 0u) q.stack[(size_t)slot * q.stack_depth + (depth - 1u)] = carried;
             alive = true;
         }
     }
     if (!alive) {
         // unwind the recursion: colour = (factor * child) * texture, innermost first (World.cpp:138,151,166)
-        for (int k = (int)depth - 1; k >= 0; k--) {
-            const float4 sk = q.stack[(size_t)k * q.capacity + slot];
-            L = (L * sk.w) * mk(sk.x, sk.y, sk.z);
+        if (!FIRST && depth != 0u) {
+            L = (L * ((carried & REF_HALF) ? 0.5f : 1.0f)) * ref_color(sc, carried);
+            const uint32_t* row = q.stack + (size_t)slot * q.stack_depth;
+            for (int k = (int)depth - 2; k >= 0; k--) {
+                const uint32_t r = row[k];
+                L = (L * ((r & REF_HALF) ? 0.5f : 1.0f)) * ref_color(sc, r);
+            }
         }
         q.radiance[slot] = make_float4(L.x, L.y, L.z, 0.0f);
         if (dbg.rng_draws) dbg.rng_draws[slot] = rng.ctr;
@@ -515,6 +528,7 @@ __global__ __launch_bounds__(256) void shade_kernel(Scene sc, Cam cam, Cfg g, Ba
     // atomic per round then reserves their places in the outgoing queue (a per-wave atomic on the one counter would
     // serialise millions of requests on a single L2 line), and the copy-out is fully coalesced.
     __shared__ float4 s_a[STILE], s_b[STILE];
+    __shared__ uint32_t s_c[STILE];
     __shared__ uint32_t s_count, s_base;
     const int qin = (pass + 1) & 1, qout = pass & 1;
     const uint32_t n_in = FIRST ? (uint32_t)bt.n_pixels * (uint32_t)(g.S * g.S) : q.counts[pass];
@@ -541,12 +555,14 @@ __global__ __launch_bounds__(256) void shade_kernel(Scene sc, Cam cam, Cfg g, Ba
         } else live = live && fetch_ray<false>(cam, g_now, bt_now, q, qin, dbg, i, ray, rng, slot, depth, false);
         bool alive = false;        // continues into the next pass
         Ray next = ray;
+        uint32_t next_ref = 0u;
         if (live) {
             const float4 hr = q.hit[i];
             if (sc.has_fog) rng.ctr = q.hit_ctr[i];      // fog volumes drew random numbers during the traversal
+            const uint32_t carried = (!FIRST && depth != 0u) ? q.c[qin][i] : 0u;
             Closest c;
             c.dist = hr.x; c.best = __float_as_int(hr.y); c.u = hr.z; c.v = hr.w; c.hit = c.best != -1;
-            alive = shade_ray<FIRST>(sc, g_now, bt_now, q, dbg, ray, rng, slot, depth, c, next);
+            alive = shade_ray<FIRST>(sc, g_now, bt_now, q, dbg, ray, rng, slot, depth, c, carried, next, next_ref);
         }
         // compact: survivors of this wave (ballot + prefix count) take consecutive places in the block's staging tile
         const unsigned long long mask = __ballot(alive);
@@ -560,6 +576,7 @@ __global__ __launch_bounds__(256) void shade_kernel(Scene sc, Cam cam, Cfg g, Ba
                 const uint32_t at = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
                 s_a[at] = make_float4(next.o.x, next.o.y, next.o.z, next.d.x);
                 s_b[at] = make_float4(next.d.y, next.d.z, __uint_as_float(slot), __uint_as_float(rng.ctr | ((depth + 1u) << 24)));
+                s_c[at] = next_ref;
             }
         }
       }
@@ -570,6 +587,7 @@ __global__ __launch_bounds__(256) void shade_kernel(Scene sc, Cam cam, Cfg g, Ba
       for (uint32_t j = threadIdx.x; j < n_out; j += 256) {
           q.a[qout][out0 + j] = s_a[j];
           q.b[qout][out0 + j] = s_b[j];
+          q.c[qout][out0 + j] = s_c[j];
       }
       __syncthreads();
     }
@@ -1008,7 +1026,9 @@ int init_engine(rt_engine* e, const rt_config* cfg) {
     HIP_TRY(hipMalloc((void**)&e->q.hit, cap * sizeof(float4)));
     HIP_TRY(hipMalloc((void**)&e->q.hit_ctr, cap * sizeof(uint32_t)));
     HIP_TRY(hipMalloc((void**)&e->q.exc, cap * sizeof(uint32_t)));      // (every ray of a pass may be handed over: a caller's own rays)
-    HIP_TRY(hipMalloc((void**)&e->q.stack, cap * sizeof(float4) * (size_t)std::max(1, cfg->bounces)));
+    for (int k = 0; k < 2; k++) HIP_TRY(hipMalloc((void**)&e->q.c[k], cap * sizeof(uint32_t)));
+    e->q.stack_depth = std::max(1, cfg->bounces);
+    HIP_TRY(hipMalloc((void**)&e->q.stack, cap * sizeof(uint32_t) * (size_t)e->q.stack_depth));
     HIP_TRY(hipMalloc((void**)&e->q.radiance, cap * sizeof(float4)));
     HIP_TRY(hipMalloc((void**)&e->d_frame, (size_t)cfg->width * cfg->height * 4));
     HIP_TRY(hipMemset(e->d_frame, 0, (size_t)cfg->width * cfg->height * 4));
@@ -1060,7 +1080,7 @@ void rt_engine_destroy(rt_engine* e) {
     free_scene(e);
     for (int k = 0; k < 2; k++) (void)hipFree(e->q.a[k]);   // (b[k] is its second half)
     (void)hipFree(e->q.hit); (void)hipFree(e->q.hit_ctr); (void)hipFree(e->q.exc);
-    (void)hipFree(e->q.stack); (void)hipFree(e->q.radiance); (void)hipFree(e->d_frame); (void)hipFree(e->d_counts_all);
+    (void)hipFree(e->q.c[0]); (void)hipFree(e->q.c[1]); (void)hipFree(e->q.stack); (void)hipFree(e->q.radiance); (void)hipFree(e->d_frame); (void)hipFree(e->d_counts_all);
     (void)hipFree(e->dbg.primary_id); (void)hipFree(e->dbg.primary_t); (void)hipFree(e->dbg.rng_draws);
     for (hipEvent_t ev : e->ev) (void)hipEventDestroy(ev);
     if (e->side_stream) { (void)hipStreamSynchronize(e->side_stream); (void)hipStreamDestroy(e->side_stream); }
@@ -1155,7 +1175,8 @@ static int rt_engine_set_scene_impl(rt_engine* e, const rt_scene* s) {
     uint8_t* texels;
     // the traversal addresses entries with 32-bit byte offsets (32 bytes each) and texels with 32-bit offsets
     if (L.ent_lo.size() >= (1u << 27) || f->objects.size() / rt::RT_OBJ_F4 > rt::SK_MASK) return fail(RT_E_INVALID, "scene too large: 2^27 entries or more, or more than 2^28 objects");
-    if (f->texels.size() >= ((size_t)1 << 32)) return fail(RT_E_INVALID, "scene too large: 4 GiB of texels or more");
+    // (a bounce records where its colour is in 29 bits: an object id, or a texel's byte offset / 4)
+    if (f->texels.size() >= ((size_t)1 << 31)) return fail(RT_E_INVALID, "scene too large: 2 GiB of texels or more");
     bool has_fog = false;
     std::vector<rt::F4> inter = device_entries(L, false, has_fog);
     if (int rc = upload(&ent, inter.data(), inter.size() * 16)) return rc;
