@@ -27,6 +27,16 @@ World::World(float time) : camera({glm::vec3{0, 3, -10}, glm::vec3{0, 0, 1}}) { 
     cfg.samples_per_axis = SAMPLES_PER_PIXEL_AXIS; cfg.bounces = LIGHT_BOUNCE_AMOUNT;
     cfg.fov = FIELD_OF_VIEW; cfg.skybox_brightness = SKYBOX_BRIGHTNESS;
     cfg.dof_intensity = DEPTH_OF_FIELD_INTENSITY; cfg.focus_distance = FOCUS_DISTANCE;
+    // FrameManager.cpp:95-107 spreads a worker's pixels over its range (stride 37) so that a frame in progress shows all
+    // over the window.  Here a frame in progress shows the batches that have finished (GetTexturePixelsToPresent), so a
+    // frame of many paths is cut into batches of 2^24 paths (3 ms of a 1080p, 64 spp, 8 bounce frame each: every
+    // presentation at 24 FPS finds new tiles) instead of the engine's 2^27 (fewest launches; what a caller who wants the
+    // finished frame only takes).  RT_PROGRESSIVE=0 keeps the engine's default.
+    {
+        const long long paths = (long long)WINDOW_WIDTH * WINDOW_HEIGHT * SAMPLES_PER_PIXEL_AXIS * SAMPLES_PER_PIXEL_AXIS;
+        const char* v = getenv("RT_PROGRESSIVE");
+        if (paths > (1ll << 25) && !(v && atoi(v) == 0)) cfg.max_batch_paths = 1 << 24;
+    }
     std::vector<int32_t> ids;
     if (const char* list = getenv("RT_DEVICES")) {
         for (const char* p = list; *p;) {
