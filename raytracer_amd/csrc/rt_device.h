@@ -159,6 +159,8 @@ struct Scene {
     int n_entries, n_tris, n_inst, fast_div_ok, idle_entry;
     int has_fog;   // some entry is a fog volume: traversal consumes random numbers (Object.cpp:579)
     int ranked;    // leaf entries carry their rank in the reference's visiting order (every scene without fog)
+    float entry_guard;   // rays that start further out (some |origin coordinate| above this) take every mesh instance's entry
+                         // box for hit: the boxes' margin is proven up to there (rt_scene.cpp, "entry boxes"); FLT_MAX without such boxes
     int has_ref;   // the entries are a regrouped layout: rays that are not ray_monotone are not walked here but handed
                    // over to the walk through the reference's layout (rt_engine.hip, exceptions)
     // distance culling (see "distance culling" below): scene-wide constants of the bound; cull_on = 0 switches it off
@@ -533,6 +535,7 @@ template <bool CULL = false>
 __device__ __forceinline__ void walker_start(const Scene& sc, const Store& st, Walker& w, const Ray ray, const Rng rng) {
     w.rng = rng;
     walker_set_ray(w, ray, sc.fast_div_ok != 0);
+    w.usable = w.usable && fmaxf(fabsf(ray.o.x), fmaxf(fabsf(ray.o.y), fabsf(ray.o.z))) <= sc.entry_guard;   // (entry boxes: see Scene)
     cull_start<CULL>(sc, w, ray);
     w.i = 0; w.resume = 0; w.inst = -1; w.stale = sc.stale_entry; w.alpha_off = -1; w.alpha_wh = 0;
     w.f0 = 0; w.f1 = 0; w.f2 = 0; w.cnt = 0; w.reach = 0.0f;
@@ -861,6 +864,7 @@ template <bool CULL, int BLOCK>
 __device__ __forceinline__ void walker_start_ord(const Scene& sc, const Store& st, Walker& w, const Ray ray, const Rng rng) {
     w.rng = rng;
     walker_set_ray(w, ray, sc.fast_div_ok != 0);
+    w.usable = w.usable && fmaxf(fabsf(ray.o.x), fmaxf(fabsf(ray.o.y), fabsf(ray.o.z))) <= sc.entry_guard;   // (entry boxes: see Scene)
     cull_start<CULL>(sc, w, ray);
     w.i = (int)st.root_link; w.resume = 0; w.inst = -1; w.stale = sc.stale_entry; w.alpha_off = -1; w.alpha_wh = 0;
     w.f0 = 0; w.f1 = 0; w.f2 = 0; w.cnt = 0; w.reach = 0.0f;
@@ -1179,16 +1183,23 @@ __device__ __forceinline__ int walker_special(const Scene& sc, const Store& st, 
     } else {
         // an inner entry tested as the reference writes it, with true divisions: a box with min > max on some axis, or
         // a ray that is not admitted to the reciprocal path
+        // (a mesh instance's entry box is proven for rays of the reciprocal path only: here it counts as hit)
+        // (dword 7 of the entry: the ordered traversal holds it — its entry may be a record of the table in LDS —, the others
+        // read it here, the traversal loop of a scene in LDS does not load it)
+        uint32_t dword7;
+        if constexpr (ORD != 0) dword7 = __float_as_uint(w.rho);
+        else dword7 = kind == rt::ENT_INNER ? reinterpret_cast<const uint32_t*>(st.ent)[8 * (size_t)w.i + 7] : 0u;
+        const bool entry_box = kind == rt::ENT_INNER && (dword7 & ~3u) == rt::ENTRY_BOX_MARK;
         if constexpr (ORD != 0) {
             // (no preference between the children here: any order gives the reference's result)
-            const bool hit = box_hit(mk(w.e01.x, w.e23.x, w.e45.x), mk(w.e01.y, w.e23.y, w.e45.y), walker_ray(w));
+            const bool hit = entry_box || box_hit(mk(w.e01.x, w.e23.x, w.e45.x), mk(w.e01.y, w.e23.y, w.e45.y), walker_ray(w));
             const uint32_t second = kind == rt::ENT_INNER ? w.sk : __float_as_uint(w.rho);
             const uint32_t first = ((uint32_t)w.i & rt::LINK_LDS) ? w.eleft : (uint32_t)w.i + 1u;
             if (hit && second != rt::LINK_NONE) ord_push(st, w, second, ORD * 4);
             w.i = hit ? (int)first : (int)ord_pop(st, w, ORD * 4);
         } else {
             const int skip = kind == rt::ENT_INNER ? (int)w.sk : __float_as_int(reinterpret_cast<const float*>(st.ent)[8 * (size_t)w.i + 7]);
-            w.i = box_hit(mk(w.e01.x, w.e23.x, w.e45.x), mk(w.e01.y, w.e23.y, w.e45.y), walker_ray(w)) ? w.i + 1 : skip;
+            w.i = (entry_box || box_hit(mk(w.e01.x, w.e23.x, w.e45.x), mk(w.e01.y, w.e23.y, w.e45.y), walker_ray(w))) ? w.i + 1 : skip;
         }
     }
     if constexpr (ORD != 0) walker_load_ord(st, w); else walker_load(st, w);

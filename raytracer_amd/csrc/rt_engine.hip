@@ -1113,7 +1113,7 @@ static std::vector<rt::F4> device_entries(const rt_layout& L, bool leaf_peer, bo
         switch (kind) {
         case rt::ENT_INNER:
             a = {lo.x, hi.x, lo.y, hi.y};
-            if (lo.x <= hi.x && lo.y <= hi.y && lo.z <= hi.z) b = {lo.z, hi.z, lo.w, L.ent_rho[i]};
+            if (lo.x <= hi.x && lo.y <= hi.y && lo.z <= hi.z) b = {lo.z, hi.z, lo.w, L.ent_entry_box[i] ? rt::bits_f((int32_t)rt::ENTRY_BOX_MARK) : L.ent_rho[i]};
             else b = {lo.z, hi.z, tag(rt::ENT_INNER_INV, 0), lo.w};
             break;
         case rt::ENT_SPHERE: a = lo; b.z = tag(kind, rt::bits_i(hi.x)); b.w = extra; break;
@@ -1235,6 +1235,7 @@ static int rt_engine_set_scene_impl(rt_engine* e, const rt_scene* s) {
     sc.has_fog = has_fog ? 1 : 0;
     sc.ranked = has_fog ? 0 : 1;
     sc.has_ref = use_fast ? 1 : 0;
+    sc.entry_guard = f->entry_guard;
     sc.cull_delta = f->cull_delta; sc.cull_cabs = f->cull_cabs; sc.cull_2rmax = f->cull_2rmax;
     sc.cull_on = (e->cfg.flags & RT_FLAG_NO_CULL) ? 0 : 1;
     // The reference's own layout beside a regrouped one: rays that the regrouped hierarchy is not proven for (a zero

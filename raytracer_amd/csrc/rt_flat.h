@@ -19,8 +19,9 @@
 //
 // Device entries (what the engine uploads, 8 dwords): dword 6 = kind << 28 | payload, so that one compare tells inner
 // entries (kind 0) from everything else and an inner entry's dword 6 IS its skip index.
-//   INNER      min.x max.x | min.y max.y | min.z max.z | skip | 0        the bounds of an axis side by side: the operand
-//                                                                        pairs of packed FP32 arithmetic
+//   INNER      min.x max.x | min.y max.y | min.z max.z | skip | rho      the bounds of an axis side by side: the operand
+//                                                                        pairs of packed FP32 arithmetic; rho: see rt_device.h,
+//                                                                        "distance culling" (ENTRY_BOX_MARK for an entry box)
 //   INNER_INV  same six bounds | kind | skip      a box with min > max on some axis (unions over negative-radius spheres,
 //                                                 Object.cpp:29-35,156-166): tested by the general slab test
 //   SPHERE     c.x c.y c.z radius 0 0 | kind, object id | 0
@@ -62,6 +63,11 @@ enum : int { ENT_INNER = 0, ENT_SPHERE = 1, ENT_CUBE = 2, ENT_TRI = 3, ENT_FOG =
 constexpr int RT_TRI_F4 = 6, RT_INST_F4 = 4, RT_OBJ_F4 = 4;
 constexpr int SK_SHIFT = 28;
 constexpr uint32_t SK_MASK = (1u << SK_SHIFT) - 1u;
+
+// dword 7 of an inner entry that is a mesh instance's entry box (rt_scene.cpp, "entry boxes"): a NaN where other inner
+// entries have their culling parameter ("never culled", like the +inf of every box over an instance), told apart by its
+// payload; the ordered entries keep the axis in the two low bits
+constexpr uint32_t ENTRY_BOX_MARK = 0x7FC00010u;
 
 constexpr uint32_t LINK_LDS = 1u << 26, LINK_INDEX = LINK_LDS - 1u, LINK_NONE = LINK_INDEX;
 constexpr int TOP_REC_DWORDS = 10;

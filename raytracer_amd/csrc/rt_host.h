@@ -80,6 +80,7 @@ struct rt_layout {
     // distances go to the leaf met first, Object.cpp:248).  0 / -1 for other kinds of entries.
     std::vector<int32_t> ent_peer;
     std::vector<uint32_t> ent_rank;
+    std::vector<uint8_t> ent_entry_box;      // 1: the inner entry is a mesh instance's entry box (rt_scene.cpp, "entry boxes")
 };
 
 // The flattened scene as the engine uploads it: the reference's layout (the base), what both layouts share, and the
@@ -93,6 +94,7 @@ struct rt_scene_flat : rt_layout {
     rt::ImageRec sky{0, 0, 0, 0};
     bool fast_div_ok = false;                // every box coordinate is 0 or has magnitude in [2^-50, 2^40] (see rt_device.h, div_by)
     float cull_delta = 0, cull_cabs = 0, cull_2rmax = 0;   // scene-wide constants of the culling bound
+    float entry_guard = 3.4028234663852886e38f;   // entry boxes are proven for rays that start within this distance of the origin, per coordinate
     bool has_fast = false;                   // `fast` is filled: some tree of the scene was regrouped
     rt_layout fast;
     int32_t regrouped_trees = 0, regrouped_groups = 0;

@@ -398,6 +398,57 @@ struct Regroup {
     }
 };
 
+// ------------------------------------------------------------------------------------------------- entry boxes
+// ApplyMovement / RotationIntersect (Object.cpp:601-608, 303-336) take every ray that reaches them into the mesh's frame
+// before the mesh's root box is tested there — and most rays then miss that box (in the default scene every ray enters
+// the tree's frame, one in six meets its box).  An entry box is a box in the SCENE's frame, tested like any inner node
+// just before the instance's entry, that contains everything a ray can hit in there: when the ray misses it, the
+// instance is not entered.  It must never be missed by a ray for which the reference's test of the root box, on the
+// transformed ray, says hit.  It is the bounding box of the root box's eight corners taken back into the scene's frame
+// (in double, by the inverse of the very matrix of float sine and cosine the transformation uses), widened by a margin
+// that covers what rounding can move: with every coordinate of the scene and of the ray's origin at most G in
+// magnitude, the transformed origin is off by at most 12 * 2^-24 G, the transformed direction by 3 * 2^-24 of its
+// length (8e-7 G of position over the 4 G a ray can travel between origin and box), and the slab test calls a box hit
+// that the ray passes within 2^-22 of the distances involved (1e-6 G): 2.5e-6 G together; the margin is 4e-5 G.  Rays
+// that start further out than G take the path of rays outside the reciprocal path, where an entry box counts as hit
+// (rt_device.h: walker_start, walker_special).
+float down(double v) { float f = (float)v; return (double)f > v ? std::nextafter(f, -INFINITY) : f; }
+float up(double v) { float f = (float)v; return (double)f < v ? std::nextafter(f, INFINITY) : f; }
+// the chain MOVE? ROT? MESH at idx: the box of the mesh's root box in the scene's frame (no margin); false for other chains
+bool entry_box(const rt_scene& s, int idx, double out[6]) {
+    double offset[3] = {0, 0, 0}, pivot[3] = {0, 0, 0}, sn = 0, cs = 1;
+    int axis = -1;
+    if (s.objs[idx].kind == MOVE) { const Vec3 o = s.objs[idx].offset; offset[0] = o.x; offset[1] = o.y; offset[2] = o.z; idx = s.objs[idx].target; }
+    if (s.objs[idx].kind == ROT) {
+        const Obj& r = s.objs[idx];
+        pivot[0] = r.pivot.x; pivot[1] = r.pivot.y; pivot[2] = r.pivot.z; axis = r.axis; sn = r.sin_t; cs = r.cos_t;
+        idx = r.target;
+    }
+    if (s.objs[idx].kind != MESH || s.objs[idx].root < 0) return false;
+    const Box3 b = s.objs[s.objs[idx].root].box;
+    const double det = cs * cs + sn * sn;
+    if (!(det > 0.5 && det < 2.0)) return false;
+    for (int k = 0; k < 3; k++) { out[k] = INFINITY; out[3 + k] = -INFINITY; }
+    for (int corner = 0; corner < 8; corner++) {
+        double p[3];
+        for (int c = 0; c < 3; c++) p[c] = ((corner >> c) & 1) ? (double)b.mx[c] : (double)b.mn[c];
+        if (axis >= 0) {
+            // forward (rt_device.h rotate_in): (a1', a2') = (cos a1 - sin a2, sin a1 + cos a2) about the pivot
+            const int a1 = axis == 0 ? 1 : 0, a2 = axis == 2 ? 1 : 2;
+            const double x = p[a1] - pivot[a1], y = p[a2] - pivot[a2];
+            p[a1] = (cs * x + sn * y) / det + pivot[a1];
+            p[a2] = (-sn * x + cs * y) / det + pivot[a2];
+        }
+        for (int c = 0; c < 3; c++) {
+            const double v = p[c] + offset[c];
+            if (!(std::fabs(v) <= 1e30)) return false;
+            out[c] = std::min(out[c], v);
+            out[3 + c] = std::max(out[3 + c], v);
+        }
+    }
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------- flattening
 struct Flattener {
     const rt_scene& s;
@@ -406,6 +457,7 @@ struct Flattener {
     std::vector<int>& tri_of;       // by object index: the triangle's record, -1 until it has one
     std::vector<int>& ent_obj;      // by entry of this layout: the object of a leaf or instance entry, -1 for other entries
     bool regroup = false;           // rebuild the upper levels of the trees that allow it
+    double entry_margin = -1;       // >= 0: mesh instances get an entry box (see entry_box) widened by this much
     int regrouped_trees = 0, regrouped_groups = 0;
     int first_leaf = -1;            // first leaf entry of the list being emitted
 
@@ -443,9 +495,23 @@ struct Flattener {
         }
         default: {   // a MOVE / ROT chain over a mesh or a fog volume = one instance
             (void)top_level;
+            double wb[6];
+            if (entry_margin >= 0 && entry_box(s, idx, wb)) {
+                // the instance's entry box: an inner entry with the instance as its only child (missed: go on behind it)
+                const float lo[3] = {down(wb[0] - entry_margin), down(wb[1] - entry_margin), down(wb[2] - entry_margin)};
+                const float hi[3] = {up(wb[3] + entry_margin), up(wb[4] + entry_margin), up(wb[5] + entry_margin)};
+                const int box_at = (int)f.ent_lo.size();
+                push({lo[0], lo[1], lo[2], bits_f(box_at + 2)}, {hi[0], hi[1], hi[2], bits_f(ENT_INNER)}, -1);
+                f.ent_right.resize(f.ent_lo.size(), -1);
+                f.ent_axis.resize(f.ent_lo.size(), 3);
+                f.ent_entry_box.resize(f.ent_lo.size(), 0);
+                f.ent_entry_box[(size_t)box_at] = 1;
+                if (first_leaf == box_at) first_leaf = box_at + 1;   // (the instance's own entry is the leaf)
+            }
+            const int inst_at = (int)f.ent_lo.size();
             push({bits_f((int)pending.size()), 0, 0, 0}, {0, 0, 0, bits_f(ENT_INSTANCE)}, idx);   // (the chain's first object stands for the instance)
             pending.push_back(idx);
-            break;
+            return inst_at;
         }
         }
         return at;
@@ -518,11 +584,12 @@ struct Flattener {
 // One layout of the scene: entries, instance records, what the ordered traversal and distance culling need per entry.
 // inst_obj: by instance of this layout, the object (wrapper chain) it stands for.
 void flatten_layout(const rt_scene& s, rt_layout& f, std::vector<F4>& tris, std::vector<int>& tri_of, std::vector<int>& ent_obj,
-                    std::vector<int>& inst_obj, bool regroup, int* regrouped_trees, int* regrouped_groups) {
+                    std::vector<int>& inst_obj, bool regroup, double entry_margin, int* regrouped_trees, int* regrouped_groups) {
     f = rt_layout();
     ent_obj.clear();
     Flattener fl{s, f, tris, tri_of, ent_obj};
     fl.regroup = regroup;
+    fl.entry_margin = entry_margin;
     fl.emit_tree(s.root, true);
     f.top_end = (int)f.ent_lo.size();
     fl.push({0, 0, 0, 0}, {0, 0, 0, bits_f(ENT_END)}, -1);
@@ -562,6 +629,7 @@ void flatten_layout(const rt_scene& s, rt_layout& f, std::vector<F4>& tris, std:
     f.ent_axis.resize(f.ent_lo.size(), 3);
     f.ent_peer.assign(f.ent_lo.size(), -1);
     f.ent_rank.assign(f.ent_lo.size(), 0u);
+    f.ent_entry_box.resize(f.ent_lo.size(), 0);
     // Ordered traversal (rt_device.h, "ordered traversal") keeps the children it has yet to visit on a per-ray stack: an
     // inner entry with two children adds one while its first child's subtree is walked, a mesh instance one (the way
     // back out) while its own tree is walked; one more slot holds the end of the top-level list.  Children follow their
@@ -610,7 +678,31 @@ void flatten(rt_scene& s) {
     rt_scene_flat& f = s.flat;
     f = rt_scene_flat();
     std::vector<int> tri_of(s.objs.size(), -1), ent_obj, inst_obj;
-    flatten_layout(s, f, f.tris, tri_of, ent_obj, inst_obj, false, nullptr, nullptr);
+    // entry boxes of mesh instances (see "entry boxes"): G = 16 x the largest coordinate of the scene, margin 4e-5 G
+    double entry_margin = -1;
+    f.entry_guard = FLT_MAX;
+    if (!getenv("RT_NO_ENTRY_BOX")) {
+        double big = 0;
+        bool any = false, fine = true;
+        auto see = [&](double v) { if (!(std::fabs(v) <= 1e30)) fine = false; else big = std::max(big, std::fabs(v)); };
+        for (size_t i = 0; i < s.objs.size(); i++) {
+            const Obj& o = s.objs[i];
+            if (o.kind == SPHERE) { for (int c = 0; c < 3; c++) { see((double)o.c[c] + std::fabs(o.r)); see((double)o.c[c] - std::fabs(o.r)); } }
+            else if (o.kind == CUBE || o.kind == NODE || o.kind == TRI || o.kind == ROT || o.kind == FOG) { for (int c = 0; c < 3; c++) { see(o.box.mn[c]); see(o.box.mx[c]); } }
+            if (o.kind == ROT) for (int c = 0; c < 3; c++) see(o.pivot[c]);
+            if (o.kind == MOVE) for (int c = 0; c < 3; c++) see(o.offset[c]);
+        }
+        for (int idx : s.top) {
+            double wb[6];
+            if (entry_box(s, idx, wb)) { any = true; for (double v : wb) see(v); }
+        }
+        if (any && fine && big > 0) {
+            const double G = 16.0 * big;
+            entry_margin = 4e-5 * G;
+            f.entry_guard = (float)G;
+        }
+    }
+    flatten_layout(s, f, f.tris, tri_of, ent_obj, inst_obj, false, entry_margin, nullptr, nullptr);
     // every leaf's place in the order in which the reference meets the leaves: the top-level list from its start, a
     // mesh's triangles where its instance's entry stands
     {
@@ -649,7 +741,7 @@ void flatten(rt_scene& s) {
     // The regrouped layout (see "regrouping"); never with fog, whose random draws follow the reference's visiting order
     if (f.fast_div_ok && !has_fog && !getenv("RT_NO_REGROUP")) {
         std::vector<int> ent_obj_fast, inst_obj_fast;
-        flatten_layout(s, f.fast, f.tris, tri_of, ent_obj_fast, inst_obj_fast, true, &f.regrouped_trees, &f.regrouped_groups);
+        flatten_layout(s, f.fast, f.tris, tri_of, ent_obj_fast, inst_obj_fast, true, entry_margin, &f.regrouped_trees, &f.regrouped_groups);
         if (f.regrouped_trees > 0) {
             f.has_fast = true;
             std::vector<int> at_fast(s.objs.size(), -1);

@@ -64,7 +64,7 @@ def test_default_scene_matches_the_reference(rt, golden, build_key):
     info = s.flat_info()
     # 19 inner + 18 leaves at the top; 511 inner + 457 triangles in the mesh; duplicate leaves listed once
     assert info["triangles"] == 457 and info["instances"] == 1 and info["objects"] == 19 and info["planes"] == 1
-    assert info["entries"] == 19 + 18 + 511 + 457 + 3      # + END of the top list, END of the mesh range, IDLE
+    assert info["entries"] == 19 + 18 + 511 + 457 + 3 + 1  # + END of the top list, END of the mesh range, IDLE; + the entry box of the tree's instance
     other = rt.default_scene(build_key + 1)
     assert not np.array_equal(other.dump_top()[1], g["top_left"]) or not np.array_equal(other.dump_top()[3], g["top_leaf_ids"])
 

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import raytracer_amd as rt
 
-scene = rt.default_scene(0x5EED0001)
+scene = rt.default_scene(int(os.environ.get("RT_BUILD_KEY", "0x5EED0001"), 0))   # RT_BUILD_KEY: another BVH build key
 e = rt.Engine(rt.default_config(width=1920, height=1080, samples_per_axis=8, bounces=8))
 e.set_scene(scene)
 e.set_camera(rt.camera_look((0.0, 3.0, -10.0), (0.0, 0.0, 1.0)))
