@@ -407,9 +407,10 @@ struct Regroup {
 // transformed ray, says hit.  It is the bounding box of the root box's eight corners taken back into the scene's frame
 // (in double, by the inverse of the very matrix of float sine and cosine the transformation uses), widened by a margin
 // that covers what rounding can move: with every coordinate of the scene and of the ray's origin at most G in
-// magnitude, the transformed origin is off by at most 12 * 2^-24 G, the transformed direction by 3 * 2^-24 of its
-// length (8e-7 G of position over the 4 G a ray can travel between origin and box), and the slab test calls a box hit
-// that the ray passes within 2^-22 of the distances involved (1e-6 G): 2.5e-6 G together; the margin is 4e-5 G.  Rays
+// magnitude, the transformed origin (two subtractions of up to 3 G, two products and a sum, the pivot added back) is off
+// by at most 24 * 2^-24 G = 1.4e-6 G, the transformed direction by 3 * 2^-24 of its length (8e-7 G of position over the
+// 4 G a ray can travel between origin and box), and the slab test, which compares quotients rounded to 2^-24 of their
+// size, calls a box hit that the ray passes within 1e-6 G: 3.2e-6 G together; the margin is 4e-5 G.  Rays
 // that start further out than G take the path of rays outside the reciprocal path, where an entry box counts as hit
 // (rt_device.h: walker_start, walker_special).
 float down(double v) { float f = (float)v; return (double)f > v ? std::nextafter(f, -INFINITY) : f; }

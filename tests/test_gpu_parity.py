@@ -667,6 +667,20 @@ def test_rays_the_regrouped_hierarchy_is_not_proven_for(rt, oracle_default, gpu_
     a, a0 = e.render_frame(3), e0.render_frame(3)
     assert_bits(a, a0, "frame through the regrouped and through the reference's hierarchy")
     assert e.stats()["box_tests"] < 0.95 * e0.stats()["box_tests"]
+    # camera rays of that kind: without a lens offset (DEPTH_OF_FIELD_INTENSITY 0) the first sample column of the pixel
+    # column at x = W / 2 looks along the camera's forward axis with d.x = 0 exactly — from in front of the tree, whose
+    # trunk they meet, those rays are handed over in the camera rays' pass
+    W, H, S, B = 64, 48, 2, 3
+    cam = rt.camera_look((0.0, 4.0, -12.0), (0.0, 0.0, 1.0))
+    p = make_engine(rt, gpu_default, W, H, S, B, cam, dof_intensity=0.0)
+    p.keep_samples(True)
+    frame = p.render_frame(11)
+    got = p.read_samples()
+    ref = oracle_default.render(cam, W, H, S, B, 11, dof=0.0, threads=4, want=("radiance", "rgba", "rng_draws", "primary_id", "primary_t"))
+    for name in ("primary_id", "primary_t", "rng_draws", "radiance"):
+        assert_bits(got[name], ref[name], f"frame without lens offsets: {name}")
+    assert_bits(frame, ref["rgba"], "frame without lens offsets")
+    assert (got["primary_id"].reshape(H, W, S * S)[:, W // 2, 0] == 2).sum() > 5      # (sample 0 of that column: the trunk)
 
 
 @pytest.mark.parametrize("case", ["single_sphere_no_plane", "single_fog", "one_pixel", "no_bounces", "max_bounces"])
