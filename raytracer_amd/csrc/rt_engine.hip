@@ -806,7 +806,8 @@ struct rt_engine {
     bool debug_valid = false;
     int n_cus = 0;
     Tune tune{32, 16, 8, 256, 16, 64, 16, 1};
-    int quorum_mem = 24;                // Tune::quorum for scenes read from memory (RT_QUORUM sets both)
+    int quorum_mem = 48;                // Tune::quorum for scenes read from memory (RT_QUORUM sets both): in effect half of the lanes that hold a
+                                        // ray (walk_round); the ordered traversal: 24 -> 55.7 ms, 32 -> 55.3, 48 -> 54.7, 56 -> 54.8 on the 960x540 cut
     int wide_blocks = -1;               // 768-thread bounce passes: -1 by batch size, 0 never, 1 always (RT_WIDE_BLOCKS)
     int refill_at_wide = 48;            // Tune::refill_at of the 768-thread camera-ray pass: with six waves per SIMD a wave can wait for
                                         // more idle lanes before it generates rays (22.59 -> 22.44 ms on the 1080p, 64 spp frame; RT_REFILL_AT sets both)
@@ -885,7 +886,7 @@ void launch_intersect(rt_engine* e, hipStream_t st, const Cfg& g, const Batch& b
     const bool fog = e->sc.has_fog != 0;
     // a scene read from memory: every iteration of the traversal loop ends in a round trip to the cache, so the loop
     // is left to the primitive tests only when fewer lanes can go on (measured on the 100 000-primitive scene: 8 -> 24
-    // lanes, 3.5 % of the frame)
+    // lanes, 3.5 % of the frame; 24 -> 48 with the ordered traversal, 2 % more)
     Tune tune = e->tune;
     if (!e->staged_bytes) tune.quorum = e->quorum_mem;
 #define RT_LAUNCH_INTERSECT(STAGED, FOG, LDS_BYTES) \
