@@ -771,6 +771,60 @@ def test_random_scenes_bit_exact(rt, orc, assets, seed, monkeypatch):
         m.close()
 
 
+def test_large_mesh_read_from_memory(rt, orc, assets):
+    """A mesh of 9 800 triangles (a bumpy sheet with the tree's cut-out texture, rotated and moved) among spheres: too large
+    for on-chip memory, so the mesh's tree is walked by the kernels of large scenes, regrouped (top-down cuts, then
+    bottom-up joins: more than 256 lowest nodes), behind its entry box, near side first.  Ids, distances, draw counts,
+    radiance and frame against the oracle bit for bit, through every combination of the engine's own shortcuts."""
+    r = np.random.default_rng(31)
+    n = 70
+    gx, gz = np.meshgrid(np.linspace(-1, 1, n + 1), np.linspace(-1, 1, n + 1), indexing="ij")
+    gy = 0.15 * np.sin(5 * gx) * np.cos(4 * gz) + 0.03 * r.normal(size=gx.shape)
+    P = np.stack([gx, gy, gz], axis=-1).astype(np.float32)
+    UV = np.stack([(gx + 1) / 2, (gz + 1) / 2], axis=-1).astype(np.float32)
+    tris = []
+    for i in range(n):
+        for j in range(n):
+            for a, b, c in (((i, j), (i + 1, j), (i, j + 1)), ((i + 1, j), (i + 1, j + 1), (i, j + 1))):
+                nrm = np.cross(P[b] - P[a], P[c] - P[a])
+                nrm = (nrm / np.linalg.norm(nrm)).astype(np.float32)
+                for v in (a, b, c):
+                    tris.append([*P[v], *UV[v], *nrm])
+    verts = np.array(tris, np.float32)
+    assert len(verts) == 3 * 2 * n * n
+    tex = np.array([[0, 0.8, 0.7, 0.6, 0, 0, 0], [1, 0.9, 0.9, 0.9, 0.2, 0.5, 0.3], [2, 0, 0, 0, 0, 0, 0]], np.float32)
+    mat = np.array([[1, 0, 0, 0, 0], [2, 1, 0, 0, 0], [1, 2, 0, 0, 0]], np.float32)
+    obj = [[3, 24.0, 1, 30.0, 1.0, 4.0, 6.0, 1, 0, 2]]                 # the mesh: size, rotation about y, offset, image texture
+    for _ in range(24):
+        c = r.uniform([-12, 0.5, -4], [12, 9, 18])
+        obj.append([0, *c, r.uniform(0.4, 2.0), 0, 0, 0, 0, int(r.integers(0, 2))])
+    obj = np.array(obj, np.float32)
+    args = (tex, mat, obj, [[0.0, 1]], verts, assets["tex"], assets["sky"], 909)
+    scene = build_table_scene(rt.Scene(), *args)
+    osc = build_table_scene(orc.Scene(orc.MATH_PORTABLE), *args)
+    info = scene.regroup_info()
+    assert info["has_regrouped_layout"] == 1 and info["lowest_nodes"] > 4000 and info["mesh_tests_regrouped"] < info["mesh_tests_reference"]
+    assert scene.flat_info()["entries"] * 32 > 80 * 1024               # not a scene for on-chip memory
+    W, H, S, B = 96, 54, 2, 4
+    cam = rt.camera_look((0.5, 13.0, -12.0), (0.0, -0.55, 1.0))
+    ref = osc.render(cam, W, H, S, B, 21, threads=8, want=("radiance", "rgba", "rng_draws", "primary_id", "primary_t"))
+    assert (ref["primary_id"] == 0).mean() > 0.08                       # the sheet is in view (much of it cut out by its texture)
+    E = rt.engine
+    counts = {}
+    for flags in (0, E.FLAG_NO_REGROUP, E.FLAG_NO_ORDER, E.FLAG_NO_CULL, E.FLAG_NO_REGROUP | E.FLAG_NO_ORDER | E.FLAG_NO_CULL):
+        e = make_engine(rt, scene, W, H, S, B, cam, flags=flags)
+        e.keep_samples(True)
+        frame = e.render_frame(21)
+        got = e.read_samples()
+        for name in ("primary_id", "primary_t", "rng_draws", "radiance"):
+            assert_bits(got[name], ref[name], f"large mesh (flags {flags}): {name}")
+        assert_bits(frame, ref["rgba"], f"large mesh (flags {flags}): frame")
+        counts[flags] = e.stats()["box_tests"]
+        e.close()
+    assert counts[0] < counts[E.FLAG_NO_REGROUP], counts
+    print(f"large mesh, slab tests per frame by flags: {counts}")
+
+
 def _culling_stress_rays(obj, rng, n_targets):
     """rays aimed at the silhouettes of spheres (where the computed distance is worst conditioned), from far away, a share
     of them nearly parallel to a coordinate axis (where a box face is crossed slowly), some with directions that are not
