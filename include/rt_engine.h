@@ -70,6 +70,11 @@ typedef struct rt_config {
  * those nodes — fewer box tests, the same leaves, the same results.  This flag makes it walk the reference's hierarchy
  * (Object.cpp:181-225) throughout — for comparisons and tests. */
 #define RT_FLAG_NO_REGROUP 8
+/* A scene that is read from device memory is walked two boxes at a time: a node's two children are tested in one step
+ * from one record and the nearer one that is hit is visited first.  This flag makes the kernel test one box per step, the
+ * child to visit first chosen by the split axis — the same results through the other variant of the kernel, for
+ * comparisons and tests. */
+#define RT_FLAG_NO_PAIRS 16
 void rt_config_defaults(rt_config* cfg);   /* the values of Constants.h:4-17 */
 
 /* ---------------------------------------------------------------------------------------------------------

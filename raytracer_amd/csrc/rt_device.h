@@ -174,6 +174,11 @@ struct OrdScene {
     const int32_t* inst_end;      // per instance: the END entry that closes its range
     int n_top_tab, stack_slots;   // records in top_tab; stack slots a ray can need
     uint32_t root_link;           // where a ray starts: entry 0, or its record in the table
+    // pair steps (see "pair steps"): the records by entry index, where a ray that enters an instance starts, and whether
+    // the scene is walked that way (then ent_ord and top_tab are the entries and the table that go with the records)
+    const float4* pair;
+    const uint32_t* inst_start;
+    int pairs;
 };
 struct Ray { V3 o, d; };
 
@@ -437,6 +442,9 @@ struct Walker {
     // ordered traversal only: LDS byte address of the lane's next free stack slot; first-child link of the table record
     // the lane stands on
     uint32_t sp, eleft;
+    // pair steps only: while the lane stands on a pair record, e01 / e23 / e45 hold the first child's box and these the
+    // second child's, the two links and the two culling parameters; while it stands on an entry, g01 holds dwords 6, 7
+    ::rtd::f2 g01, g23, g45, lk, rh;
 };
 // entries (and, when staged, triangles) either in LDS or in global memory
 struct Store {
@@ -445,6 +453,7 @@ struct Store {
     // upper-level records and of slot 0 of thread 0's stack
     uint32_t* lds0; uint32_t lds0_addr, top_addr, stack_addr;
     uint32_t root_link; const int32_t* inst_end;   // where a ray starts; per instance the END entry that closes its range
+    const float4* pair; const uint32_t* inst_start;   // pair steps: the records by entry index; per instance where a ray starts in it
 };
 
 __device__ __forceinline__ Ray walker_ray(const Walker& w) {
@@ -473,6 +482,8 @@ __device__ __forceinline__ void walker_idle(const Scene& sc, Walker& w) {
     w.s0 = w.p0; w.s1 = w.p1; w.s2 = w.p2; w.s3 = w.p3; w.s4 = w.p4; w.s_usable = true;
     w.resume = 0; w.inst = -1; w.stale = -1; w.alpha_off = -1; w.alpha_wh = 0;
     w.f0 = 0; w.f1 = 0; w.f2 = 0; w.cnt = 0; w.reach = 0.0f;
+    w.g01 = f2{__uint_as_float(w.sk), 0.0f}; w.g23 = f2{0, 0}; w.g45 = f2{0, 0}; w.lk = f2{0, 0}; w.rh = f2{0, 0};   // (pair steps: the idle entry as its loop sees it)
+    w.sp = 0; w.eleft = 0;
     w.rng.key = 0; w.rng.ctr = 0;
     w.c.dist = FLT_MAX; w.c.best = -1; w.c.u = 0; w.c.v = 0; w.c.hit = false;
 }
@@ -1038,6 +1049,276 @@ __device__ __forceinline__ void box_steps_ord(const Store& st, Walker& w, int qu
     n_box += nb;
 }
 
+// ---------------------------------------------------------------------------------------------------- pair steps
+// The ordered traversal above tests one box per step: a lane loads a node, tests its box, and pops when it misses —
+// half of all steps on large scenes are such misses, each a round trip to memory.  Pair steps test a node's TWO children
+// in one step, from one record that holds both boxes (rt_flat.h, "Pair records"): a child that is missed or culled costs
+// its share of the arithmetic and nothing else; of two children that are hit the one the ray enters FIRST (by the entry
+// distances just computed, not by a guess from the split axis) is visited first and the other waits on the stack.
+// Nothing is tested that the reference does not test, and a node's own box need not be tested on arrival: it was, as
+// its parent's child — and for a root (the scene's, a mesh's) not at all, because a box that is missed contains no box
+// that is hit (rt_scene.cpp, "regrouping": the slab test is monotone in the box), so the first pair step finds nothing.
+// Per iteration, for the lanes that act:
+//   * lanes on a pair record: both slab tests and culling bounds as in box_steps_ord; then go to the nearer child that
+//     is hit, push the other if it is hit too, pop if none is;
+//   * lanes on a leaf entry with room in their FIFO: note it; go on to the next entry when the leaf says that its sibling
+//     follows (LEAF_MORE), else pop;
+//   * both: fetch the record or entry they stand on now (records of the tree's upper levels from the table in LDS).
+// Every other entry (end of a list, instance, a box with min > max, an instance's entry box, an inner entry reached as
+// an entry) and every ray outside the reciprocal path waits for walker_special.
+// Registers: the record occupies v16..v31 (four 16-byte loads); an entry its first half, dword 6 in v22, dword 7 in v23.
+template <int BLOCK>
+__device__ __forceinline__ void box_steps_pairs(const Store& st, Walker& w, int quorum, uint32_t& n_box) {
+    const unsigned long long px = __ballot(w.p3.x >= 0), py = __ballot(w.p3.y >= 0), pz = __ballot(w.p4.x >= 0);
+    const unsigned long long usable = __ballot(w.usable);
+    unsigned long long m, m2, m3, m4, mall, saved, mhit, mpop, ma, mb;
+    int n_pair;
+    uint32_t nb = 0;
+    const float4* base = st.ent;
+    const float4* pbase = st.pair;
+    const uint32_t ldsbase = st.top_addr;
+    asm volatile(
+             "s_mov_b64 %[saved], exec\n\t"
+             "1:\n\t"
+             "v_cmp_le_u32_e32 vcc, 0x40000000, %[i]\n\t"           // lanes on a pair record
+             "s_and_b64 %[m], vcc, %[usable]\n\t"
+             "v_add_u32_e32 v9, 0xf0000000, v22\n\t"                // an entry's dword 6
+             "v_cmp_gt_u32_e64 %[m2], 3, %[cnt]\n\t"
+             "s_andn2_b64 %[m2], %[m2], vcc\n\t"
+             "v_cmp_gt_u32_e32 vcc, 0x40000000, v9\n\t"             // kinds 1..4: a leaf
+             "s_and_b64 %[m2], %[m2], vcc\n\t"
+             "s_or_b64 %[mall], %[m], %[m2]\n\t"
+             "s_cmp_eq_u64 %[mall], 0\n\t"
+             "s_cbranch_scc1 2f\n\t"
+             "s_mov_b64 %[mpop], 0\n\t"
+             "s_cmp_eq_u64 %[m], 0\n\t"
+             "s_cbranch_scc1 3f\n\t"
+             "s_and_b64 exec, %[saved], %[m]\n\t"
+             // both children on one-multiplication quotients: A into v8 (entry), v3 (exit); B into v4, v5
+             "v_pk_add_f32 v[10:11], v[16:17], %[p0] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+             "v_pk_add_f32 v[12:13], v[18:19], %[p0] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+             "v_pk_add_f32 v[14:15], v[20:21], %[p1] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+             "v_pk_mul_f32 v[10:11], v[10:11], %[p1] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+             "v_pk_mul_f32 v[12:13], v[12:13], %[p2] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+             "v_pk_mul_f32 v[14:15], v[14:15], %[p2] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+             "v_pk_add_f32 v[4:5], v[22:23], %[p0] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+             "v_pk_add_f32 v[6:7], v[24:25], %[p0] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+             "v_cndmask_b32_e64 v8, v11, v10, %[px]\n\t"
+             "v_cndmask_b32_e64 v3, v10, v11, %[px]\n\t"
+             "v_cndmask_b32_e64 v2, v13, v12, %[py]\n\t"
+             "v_cndmask_b32_e64 v9, v12, v13, %[py]\n\t"
+             "v_cndmask_b32_e64 v10, v15, v14, %[pz]\n\t"
+             "v_cndmask_b32_e64 v11, v14, v15, %[pz]\n\t"
+             "v_pk_add_f32 v[12:13], v[26:27], %[p1] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+             "v_max3_f32 v8, v8, v2, v10\n\t"
+             "v_min3_f32 v3, v3, v9, v11\n\t"
+             "v_pk_mul_f32 v[4:5], v[4:5], %[p1] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+             "v_pk_mul_f32 v[6:7], v[6:7], %[p2] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+             "v_pk_mul_f32 v[12:13], v[12:13], %[p2] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+             "v_sub_u32_e32 v14, v3, v8\n\t"                       // A: entry and exit within 2^-20 of each other?
+             "v_add_u32_e32 v14, 32, v14\n\t"
+             "v_cndmask_b32_e64 v2, v5, v4, %[px]\n\t"
+             "v_cndmask_b32_e64 v5, v4, v5, %[px]\n\t"
+             "v_cndmask_b32_e64 v9, v7, v6, %[py]\n\t"
+             "v_cndmask_b32_e64 v7, v6, v7, %[py]\n\t"
+             "v_cndmask_b32_e64 v10, v13, v12, %[pz]\n\t"
+             "v_cndmask_b32_e64 v13, v12, v13, %[pz]\n\t"
+             "v_max3_f32 v4, v2, v9, v10\n\t"
+             "v_min3_f32 v5, v5, v7, v13\n\t"
+             "v_cmp_gt_u32_e64 %[m3], 64, v14\n\t"
+             "v_sub_u32_e32 v15, v5, v4\n\t"                       // B likewise
+             "v_add_u32_e32 v15, 32, v15\n\t"
+             "v_cmp_gt_u32_e64 %[m4], 64, v15\n\t"
+             "s_or_b64 %[m3], %[m3], %[m4]\n\t"
+             "s_cmp_eq_u64 %[m3], 0\n\t"
+             "s_cbranch_scc1 5f\n\t"
+             // some lane is that close: the exactly rounded quotients for both children (div_by, two lanes wide)
+             "v_pk_add_f32 v[10:11], v[16:17], %[p0] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+             "v_pk_mul_f32 v[2:3], v[10:11], %[p1] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+             "v_pk_fma_f32 v[14:15], %[p3], v[2:3], v[10:11] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+             "v_pk_fma_f32 v[2:3], v[14:15], %[p1], v[2:3] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+             "v_pk_fma_f32 v[14:15], %[p3], v[2:3], v[10:11] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+             "v_pk_fma_f32 v[2:3], v[14:15], %[p1], v[2:3] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+             "v_pk_add_f32 v[10:11], v[18:19], %[p0] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+             "v_pk_mul_f32 v[6:7], v[10:11], %[p2] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+             "v_pk_fma_f32 v[14:15], %[p3], v[6:7], v[10:11] op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+             "v_pk_fma_f32 v[6:7], v[14:15], %[p2], v[6:7] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+             "v_pk_fma_f32 v[14:15], %[p3], v[6:7], v[10:11] op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+             "v_pk_fma_f32 v[6:7], v[14:15], %[p2], v[6:7] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+             "v_pk_add_f32 v[10:11], v[20:21], %[p1] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+             "v_pk_mul_f32 v[12:13], v[10:11], %[p2] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+             "v_pk_fma_f32 v[14:15], %[p4], v[12:13], v[10:11] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+             "v_pk_fma_f32 v[12:13], v[14:15], %[p2], v[12:13] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+             "v_pk_fma_f32 v[14:15], %[p4], v[12:13], v[10:11] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+             "v_pk_fma_f32 v[12:13], v[14:15], %[p2], v[12:13] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+             "v_cndmask_b32_e64 v8, v3, v2, %[px]\n\t"
+             "v_cndmask_b32_e64 v3, v2, v3, %[px]\n\t"
+             "v_cndmask_b32_e64 v9, v7, v6, %[py]\n\t"
+             "v_cndmask_b32_e64 v7, v6, v7, %[py]\n\t"
+             "v_cndmask_b32_e64 v10, v13, v12, %[pz]\n\t"
+             "v_cndmask_b32_e64 v13, v12, v13, %[pz]\n\t"
+             "v_max3_f32 v8, v8, v9, v10\n\t"
+             "v_min3_f32 v3, v3, v7, v13\n\t"
+             "v_pk_add_f32 v[10:11], v[22:23], %[p0] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+             "v_pk_mul_f32 v[4:5], v[10:11], %[p1] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+             "v_pk_fma_f32 v[14:15], %[p3], v[4:5], v[10:11] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+             "v_pk_fma_f32 v[4:5], v[14:15], %[p1], v[4:5] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+             "v_pk_fma_f32 v[14:15], %[p3], v[4:5], v[10:11] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+             "v_pk_fma_f32 v[4:5], v[14:15], %[p1], v[4:5] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+             "v_pk_add_f32 v[10:11], v[24:25], %[p0] op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+             "v_pk_mul_f32 v[6:7], v[10:11], %[p2] op_sel:[0,0] op_sel_hi:[1,0]\n\t"
+             "v_pk_fma_f32 v[14:15], %[p3], v[6:7], v[10:11] op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+             "v_pk_fma_f32 v[6:7], v[14:15], %[p2], v[6:7] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+             "v_pk_fma_f32 v[14:15], %[p3], v[6:7], v[10:11] op_sel:[1,0,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+             "v_pk_fma_f32 v[6:7], v[14:15], %[p2], v[6:7] op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"
+             "v_pk_add_f32 v[10:11], v[26:27], %[p1] op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]\n\t"
+             "v_pk_mul_f32 v[12:13], v[10:11], %[p2] op_sel:[0,1] op_sel_hi:[1,1]\n\t"
+             "v_pk_fma_f32 v[14:15], %[p4], v[12:13], v[10:11] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+             "v_pk_fma_f32 v[12:13], v[14:15], %[p2], v[12:13] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+             "v_pk_fma_f32 v[14:15], %[p4], v[12:13], v[10:11] op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]\n\t"
+             "v_pk_fma_f32 v[12:13], v[14:15], %[p2], v[12:13] op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+             "v_cndmask_b32_e64 v2, v5, v4, %[px]\n\t"
+             "v_cndmask_b32_e64 v5, v4, v5, %[px]\n\t"
+             "v_cndmask_b32_e64 v9, v7, v6, %[py]\n\t"
+             "v_cndmask_b32_e64 v7, v6, v7, %[py]\n\t"
+             "v_cndmask_b32_e64 v10, v13, v12, %[pz]\n\t"
+             "v_cndmask_b32_e64 v13, v12, v13, %[pz]\n\t"
+             "v_max3_f32 v4, v2, v9, v10\n\t"
+             "v_min3_f32 v5, v5, v7, v13\n\t"
+             "5:\n\t"
+             // hit: entry <= exit, exit not negative, entry not beyond the culling bound of the child
+             "v_fma_f32 v6, %[ck], v30, %[cbase]\n\t"
+             "v_fma_f32 v7, %[ck], v31, %[cbase]\n\t"
+             "v_cmp_le_f32_e32 vcc, v8, v3\n\t"
+             "v_cmp_nlt_f32_e64 %[m3], v3, 0\n\t"
+             "v_cmp_ngt_f32_e64 %[m4], v8, v6\n\t"
+             "s_and_b64 %[ma], vcc, %[m3]\n\t"
+             "s_and_b64 %[ma], %[ma], %[m4]\n\t"
+             "v_cmp_le_f32_e32 vcc, v4, v5\n\t"
+             "v_cmp_nlt_f32_e64 %[m3], v5, 0\n\t"
+             "v_cmp_ngt_f32_e64 %[m4], v4, v7\n\t"
+             "s_and_b64 %[mb], vcc, %[m3]\n\t"
+             "s_and_b64 %[mb], %[mb], %[m4]\n\t"
+             "s_and_b64 %[mhit], %[ma], %[mb]\n\t"                  // both: the one entered first goes first
+             "v_cmp_lt_f32_e32 vcc, v4, v8\n\t"
+             "s_and_b64 vcc, vcc, %[mhit]\n\t"
+             "s_andn2_b64 %[m3], %[ma], vcc\n\t"                    // lanes that go to A
+             "s_or_b64 %[m4], %[ma], %[mb]\n\t"
+             "s_andn2_b64 %[mpop], %[m], %[m4]\n\t"                 // neither: pop
+             "v_cndmask_b32_e64 v6, v29, v28, %[m3]\n\t"
+             "v_cndmask_b32_e64 v7, v28, v29, %[m3]\n\t"
+             "s_mov_b64 exec, %[mhit]\n\t"
+             "ds_write_b32 %[sp], v7\n\t"
+             "v_add_u32_e32 %[sp], %[stride], %[sp]\n\t"
+             "s_mov_b64 exec, %[m4]\n\t"
+             "v_mov_b32_e32 %[i], v6\n\t"
+             "3:\n\t"
+             "s_cmp_eq_u64 %[m2], 0\n\t"
+             "s_cbranch_scc1 4f\n\t"
+             "s_and_b64 exec, %[saved], %[m2]\n\t"
+             "v_cmp_eq_u32_e64 %[m3], 0, %[cnt]\n\t"
+             "v_cmp_eq_u32_e32 vcc, 1, %[cnt]\n\t"
+             "v_mov_b32_e32 %[f2], %[i]\n\t"
+             "v_add_u32_e32 %[cnt], 1, %[cnt]\n\t"
+             "v_cndmask_b32_e64 %[f0], %[f0], %[i], %[m3]\n\t"
+             "v_cndmask_b32_e32 %[f1], %[f1], %[i], vcc\n\t"
+             "v_cmp_gt_i32_e32 vcc, 0, v23\n\t"                     // LEAF_MORE: the sibling leaf is the next entry
+             "v_add_u32_e32 v2, 1, %[i]\n\t"
+             "s_andn2_b64 %[m3], exec, vcc\n\t"
+             "s_or_b64 %[mpop], %[mpop], %[m3]\n\t"
+             "v_cndmask_b32_e32 %[i], %[i], v2, vcc\n\t"
+             "4:\n\t"
+             "s_cmp_eq_u64 %[mpop], 0\n\t"
+             "s_cbranch_scc1 6f\n\t"
+             "s_mov_b64 exec, %[mpop]\n\t"
+             "v_subrev_u32_e32 %[sp], %[stride], %[sp]\n\t"
+             "ds_read_b32 %[i], %[sp]\n\t"
+             "s_waitcnt lgkmcnt(0)\n\t"
+             "6:\n\t"
+             // fetch: an entry (two loads), a record from memory (four), or a record from the table in LDS
+             "s_and_b64 exec, %[saved], %[mall]\n\t"
+             "v_cmp_le_u32_e32 vcc, 0x40000000, %[i]\n\t"
+             "s_and_b64 %[m3], vcc, exec\n\t"                       // records
+             "s_andn2_b64 exec, exec, vcc\n\t"                      // entries
+             "s_cbranch_execz 7f\n\t"
+             "v_lshlrev_b32_e32 v2, 5, %[i]\n\t"
+             "global_load_dwordx4 v[16:19], v2, %[base]\n\t"
+             "global_load_dwordx4 v[20:23], v2, %[base] offset:16\n\t"
+             "7:\n\t"
+             "s_mov_b64 exec, %[m3]\n\t"
+             "s_cbranch_execz 9f\n\t"
+             "v_and_b32_e32 v3, 0x4000000, %[i]\n\t"
+             "v_and_b32_e32 v2, 0x3ffffff, %[i]\n\t"
+             "v_cmp_ne_u32_e32 vcc, 0, v3\n\t"
+             "s_and_b64 %[m4], vcc, exec\n\t"                       // records in LDS
+             "s_andn2_b64 exec, exec, vcc\n\t"                      // records in memory
+             "s_cbranch_execz 8f\n\t"
+             "v_lshlrev_b32_e32 v3, 6, v2\n\t"
+             "global_load_dwordx4 v[16:19], v3, %[pbase]\n\t"
+             "global_load_dwordx4 v[20:23], v3, %[pbase] offset:16\n\t"
+             "global_load_dwordx4 v[24:27], v3, %[pbase] offset:32\n\t"
+             "global_load_dwordx4 v[28:31], v3, %[pbase] offset:48\n\t"
+             "8:\n\t"
+             "s_mov_b64 exec, %[m4]\n\t"
+             "s_cbranch_execz 9f\n\t"
+             "v_lshl_add_u32 v2, v2, 6, %[ldsbase]\n\t"
+             "ds_read_b128 v[16:19], v2\n\t"
+             "ds_read_b128 v[20:23], v2 offset:16\n\t"
+             "ds_read_b128 v[24:27], v2 offset:32\n\t"
+             "ds_read_b128 v[28:31], v2 offset:48\n\t"
+             "9:\n\t"
+             "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"
+             "s_mov_b64 exec, %[saved]\n\t"
+             "s_bcnt1_i32_b64 %[cntS], %[m]\n\t"
+             "s_add_u32 %[nbox], %[nbox], %[cntS]\n\t"
+             "s_add_u32 %[nbox], %[nbox], %[cntS]\n\t"
+             "s_cmp_ge_u32 %[cntS], %[quorum]\n\t"
+             "s_cbranch_scc1 1b\n\t"
+             "2:\n\t"
+             : [e01] "+{v[16:17]}"(w.e01), [e23] "+{v[18:19]}"(w.e23), [e45] "+{v[20:21]}"(w.e45), [g01] "+{v[22:23]}"(w.g01), [g23] "+{v[24:25]}"(w.g23),
+               [g45] "+{v[26:27]}"(w.g45), [lk] "+{v[28:29]}"(w.lk), [rh] "+{v[30:31]}"(w.rh), [i] "+v"(w.i), [f0] "+v"(w.f0),
+               [f1] "+v"(w.f1), [f2] "+v"(w.f2), [cnt] "+v"(w.cnt), [m] "=&s"(m), [m2] "=&s"(m2), [m3] "=&s"(m3),
+               [mall] "=&s"(mall), [saved] "=&s"(saved), [cntS] "=&s"(n_pair), [m4] "=&s"(m4), [nbox] "+s"(nb),
+               [mhit] "=&s"(mhit), [mpop] "=&s"(mpop), [ma] "=&s"(ma), [mb] "=&s"(mb), [sp] "+v"(w.sp)
+             : [p0] "v"(w.p0), [p1] "v"(w.p1), [p2] "v"(w.p2), [p3] "v"(w.p3), [p4] "v"(w.p4), [px] "s"(px), [py] "s"(py),
+               [pz] "s"(pz), [base] "s"(base), [pbase] "s"(pbase), [usable] "s"(usable), [quorum] "s"(quorum), [ck] "v"(w.cull_k), [cbase] "v"(w.cull_base),
+               [ldsbase] "s"(ldsbase), [stride] "n"(BLOCK * 4)
+             : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "vcc", "scc", "memory");
+    n_box += nb;
+}
+// What the lane stands on, for the code around the loop: a pair record reads as an inner entry (kind 0), an entry as itself
+__device__ __forceinline__ void pairs_sync_kind(Walker& w) {
+    const bool on_record = ((uint32_t)w.i & rt::LINK_PAIR) != 0u;
+    w.sk = on_record ? 0u : __float_as_uint(w.g01.x);
+    w.rho = on_record ? 0.0f : w.g01.y;
+}
+__device__ __forceinline__ void walker_load_pairs(const Store& st, Walker& w) {
+    const uint32_t i = (uint32_t)w.i;
+    if (i & rt::LINK_PAIR) {
+        const uint32_t* r = (i & rt::LINK_LDS) ? st.lds0 + ((st.top_addr - st.lds0_addr) >> 2) + rt::PAIR_REC_DWORDS * (i & rt::LINK_INDEX)
+                                               : reinterpret_cast<const uint32_t*>(st.pair) + rt::PAIR_REC_DWORDS * (size_t)(i & rt::LINK_INDEX);
+        auto pr = [&](int k) { return f2{__uint_as_float(r[k]), __uint_as_float(r[k + 1])}; };
+        w.e01 = pr(0); w.e23 = pr(2); w.e45 = pr(4); w.g01 = pr(6); w.g23 = pr(8); w.g45 = pr(10); w.lk = pr(12); w.rh = pr(14);
+    } else {
+        // (every field is assigned on both sides: a field assigned on one side only makes the compiler keep it in memory)
+        const f2* e = reinterpret_cast<const f2*>(st.ent) + 4 * (size_t)i;
+        w.e01 = e[0]; w.e23 = e[1]; w.e45 = e[2]; w.g01 = e[3]; w.g23 = f2{0, 0}; w.g45 = f2{0, 0}; w.lk = f2{0, 0}; w.rh = f2{0, 0};
+    }
+    pairs_sync_kind(w);
+}
+template <bool CULL, int BLOCK>
+__device__ __forceinline__ void walker_start_pairs(const Scene& sc, const Store& st, Walker& w, const Ray ray, const Rng rng) {
+    w.rng = rng;
+    walker_set_ray(w, ray, sc.fast_div_ok != 0);
+    w.usable = w.usable && fmaxf(fabsf(ray.o.x), fmaxf(fabsf(ray.o.y), fabsf(ray.o.z))) <= sc.entry_guard;   // (entry boxes: see Scene)
+    cull_start<CULL>(sc, w, ray);
+    w.i = (int)st.root_link; w.resume = 0; w.inst = -1; w.stale = sc.stale_entry; w.alpha_off = -1; w.alpha_wh = 0;
+    w.f0 = 0; w.f1 = 0; w.f2 = 0; w.cnt = 0; w.reach = 0.0f;
+    w.c.dist = FLT_MAX; w.c.best = -1; w.c.u = 0; w.c.v = 0; w.c.hit = false;
+    w.sp = st.stack_addr + 4u * ((uint32_t)BLOCK + threadIdx.x);     // slot 1: slot 0 holds the end of the top-level list
+    walker_load_pairs(st, w);
+}
+
 // A lane's queue position as the kernels that read the ray again keep it: the top bit carries Walker::usable of the ray
 // as given (queues hold fewer than 2^31 positions)
 constexpr uint32_t IDX_MASK = 0x7FFFFFFFu, IDX_USABLE = 0x80000000u;
@@ -1133,11 +1414,26 @@ __device__ __forceinline__ void tri_finish_step(const Scene& sc, const Store& st
 // enters a mesh instance and has, in the instance's frame, a zero direction component (ray_monotone) cannot be walked
 // here; the lane goes idle and the caller hands the ray over to the walk through the reference's layout.
 enum : int { WALK_ON = 0, WALK_DONE = 1, WALK_HANDED_OVER = 2 };
-template <bool RELOAD = false, bool LEAN = false, bool SAVE = false, int ORD = 0>
+// PAIRS (with ORD): pair steps; a lane on a pair record comes here when its ray is outside the reciprocal path, and an
+// inner entry reached as an entry (a root that has no record, a box with min > max, an instance's entry box) always.
+template <bool RELOAD = false, bool LEAN = false, bool SAVE = false, int ORD = 0, bool PAIRS = false>
 __device__ __forceinline__ int walker_special(const Scene& sc, const Store& st, Walker& w, float4* outer_a = nullptr, float4* outer_b = nullptr, uint32_t outer_tagged = 0) {
     const uint32_t outer_idx = outer_tagged & IDX_MASK;
     int done = WALK_ON;
     const int kind = sk_kind(w.sk);
+    if constexpr (PAIRS) {
+        if ((uint32_t)w.i & rt::LINK_PAIR) {
+            // both children as the reference tests them; any order of the two gives the reference's result
+            const Ray r = walker_ray(w);
+            const bool ha = box_hit(mk(w.e01.x, w.e23.x, w.e45.x), mk(w.e01.y, w.e23.y, w.e45.y), r);
+            const bool hb = box_hit(mk(w.g01.x, w.g23.x, w.g45.x), mk(w.g01.y, w.g23.y, w.g45.y), r);
+            const uint32_t la = __float_as_uint(w.lk.x), lb = __float_as_uint(w.lk.y);
+            if (ha && hb) ord_push(st, w, lb, ORD * 4);
+            w.i = ha ? (int)la : (hb ? (int)lb : (int)ord_pop(st, w, ORD * 4));
+            walker_load_pairs(st, w);
+            return WALK_ON;
+        }
+    }
     if (kind == rt::ENT_END) {
         if (w.inst >= 0) {   // PolygonMesh and its wrappers return to the top level
             if constexpr (ORD != 0) w.i = (int)ord_pop(st, w, ORD * 4);
@@ -1176,6 +1472,7 @@ __device__ __forceinline__ int walker_special(const Scene& sc, const Store& st, 
         w.inst = ii;
         if (!LEAN) { w.alpha_off = __float_as_int(i3.z); w.alpha_wh = __float_as_uint(i3.w); }   // alpha cut-out of the mesh's texture, or -1
         w.i = __float_as_int(i2.z);
+        if constexpr (PAIRS) w.i = (int)st.inst_start[ii];   // (the mesh's root: its pair record if it has one)
         if (sc.has_ref && !w.usable && !ray_monotone(walker_ray(w))) {   // not a ray for this layout: hand it over, as it was given
             w.i = sc.idle_entry; w.inst = -1; w.cnt = 0; w.reach = 0.0f;
             done = WALK_HANDED_OVER;
@@ -1195,20 +1492,23 @@ __device__ __forceinline__ int walker_special(const Scene& sc, const Store& st, 
             const bool hit = entry_box || box_hit(mk(w.e01.x, w.e23.x, w.e45.x), mk(w.e01.y, w.e23.y, w.e45.y), walker_ray(w));
             const uint32_t second = kind == rt::ENT_INNER ? w.sk : __float_as_uint(w.rho);
             const uint32_t first = ((uint32_t)w.i & rt::LINK_LDS) ? w.eleft : (uint32_t)w.i + 1u;
-            if (hit && second != rt::LINK_NONE) ord_push(st, w, second, ORD * 4);
-            w.i = hit ? (int)first : (int)ord_pop(st, w, ORD * 4);
+            if (PAIRS && kind == rt::ENT_INNER && (second & rt::LINK_PAIR)) w.i = hit ? (int)second : (int)ord_pop(st, w, ORD * 4);   // its record takes over
+            else {
+                if (hit && second != rt::LINK_NONE) ord_push(st, w, second, ORD * 4);
+                w.i = hit ? (int)first : (int)ord_pop(st, w, ORD * 4);
+            }
         } else {
             const int skip = kind == rt::ENT_INNER ? (int)w.sk : __float_as_int(reinterpret_cast<const float*>(st.ent)[8 * (size_t)w.i + 7]);
             w.i = (entry_box || box_hit(mk(w.e01.x, w.e23.x, w.e45.x), mk(w.e01.y, w.e23.y, w.e45.y), walker_ray(w))) ? w.i + 1 : skip;
         }
     }
-    if constexpr (ORD != 0) walker_load_ord(st, w); else walker_load(st, w);
+    if constexpr (PAIRS) walker_load_pairs(st, w); else if constexpr (ORD != 0) walker_load_ord(st, w); else walker_load(st, w);
     return done;
 }
 // One round for a wave: the traversal loop; then primitive tests, repeated while at least `prim_quorum` lanes have a
 // noted leaf; then the state-changing entries of lanes that have none left.  Returns, per lane, what walker_special
 // returned: WALK_DONE in lanes whose ray finished, WALK_HANDED_OVER in lanes whose ray has to be walked elsewhere.
-template <bool LDS, bool FOG, bool RELOAD = false, bool SAVE = false, int ORD = 0>
+template <bool LDS, bool FOG, bool RELOAD = false, bool SAVE = false, int ORD = 0, bool PAIRS = false>
 __device__ __forceinline__ int walk_round(const Scene& sc, const Store& st, Walker& w, int quorum, int prim_quorum, int finish_quorum, Prof& prof, uint32_t& n_box,
                                            float4* outer_a = nullptr, float4* outer_b = nullptr, uint32_t outer_idx = 0, float4* hit_rec = nullptr, const uint32_t* idx_slots = nullptr) {
     RT_PROF(unsigned long long t0 = __builtin_readcyclecounter(); prof.rounds++;)
@@ -1219,7 +1519,8 @@ __device__ __forceinline__ int walk_round(const Scene& sc, const Store& st, Walk
     prim_quorum = max(1, min(prim_quorum, (busy + 1) >> 1));
     finish_quorum = max(1, min(finish_quorum, (busy + 1) >> 1));
     constexpr bool CULL = !LDS && !FOG;   // see "distance culling": large scenes, and never when traversal draws random numbers
-    if constexpr (ORD != 0) box_steps_ord<ORD>(st, w, quorum, n_box); else box_steps<LDS>(st, w, quorum, prof, n_box);
+    if constexpr (PAIRS) { box_steps_pairs<ORD>(st, w, quorum, n_box); pairs_sync_kind(w); }
+    else if constexpr (ORD != 0) box_steps_ord<ORD>(st, w, quorum, n_box); else box_steps<LDS>(st, w, quorum, prof, n_box);
     RT_PROF(unsigned long long t1 = __builtin_readcyclecounter(); prof.box += t1 - t0;)
     for (;;) {
         const bool has = w.cnt != 0 && w.reach == 0.0f;
@@ -1241,8 +1542,9 @@ __device__ __forceinline__ int walk_round(const Scene& sc, const Store& st, Walk
     }
     RT_PROF(unsigned long long t2 = __builtin_readcyclecounter(); prof.prim += t2 - t1;)
     const int kind = sk_kind(w.sk);
+    const bool as_entry = PAIRS && !((uint32_t)w.i & rt::LINK_PAIR);   // pair steps: the loop does not test an inner entry reached as an entry
     const bool special = w.cnt == 0 && (kind == rt::ENT_END || kind == rt::ENT_INSTANCE || kind == rt::ENT_INNER_INV ||
-                                        (kind == rt::ENT_INNER && !w.usable));
+                                        (kind == rt::ENT_INNER && (!w.usable || as_entry)));
     int done = WALK_ON;
     RT_PROF(if (__any(special)) prof.specials++;)
 #ifdef RT_PROFILE
@@ -1260,7 +1562,8 @@ __device__ __forceinline__ int walk_round(const Scene& sc, const Store& st, Walk
     }
 #endif
     n_box += (uint32_t)__popcll(__ballot(special && (kind == rt::ENT_INNER_INV || kind == rt::ENT_INNER)));   // boxes tested as written
-    if (special) done = walker_special<RELOAD, RELOAD && LDS, SAVE, ORD>(sc, st, w, outer_a, outer_b, idx_slots ? idx_slots[lane_now()] : outer_idx);
+    if (PAIRS) n_box += (uint32_t)__popcll(__ballot(special && kind == rt::ENT_INNER && !as_entry));   // (a record: two boxes)
+    if (special) done = walker_special<RELOAD, RELOAD && LDS, SAVE, ORD, PAIRS>(sc, st, w, outer_a, outer_b, idx_slots ? idx_slots[lane_now()] : outer_idx);
     RT_PROF(prof.special += __builtin_readcyclecounter() - t2;)
     return done;
 }

@@ -216,18 +216,20 @@ __device__ __forceinline__ bool fetch_ray(const Cam& cam, const Cfg& g, const Ba
 // copied once; blocks are persistent), or global memory when the scene is too large for that.
 // ORD_BLOCK > 0 (the ordered traversal, blocks of ORD_BLOCK threads): the block's LDS holds the threads' stacks (slot s
 // of thread t at dword s * ORD_BLOCK + t) and behind them the table of the tree's upper levels, copied here once.
-template <bool STAGED, int ORD_BLOCK = 0>
+template <bool STAGED, int ORD_BLOCK = 0, bool PAIRS = false>
 __device__ __forceinline__ Store stage_scene(const Scene& sc, float4* smem, const OrdScene* os = nullptr) {
     Store st;
     st.lds0 = nullptr; st.lds0_addr = 0; st.top_addr = 0; st.stack_addr = 0; st.root_link = 0; st.inst_end = nullptr;
+    st.pair = nullptr; st.inst_start = nullptr;
     if (ORD_BLOCK) {
         uint32_t* l = reinterpret_cast<uint32_t*>(smem);
-        const int stack_dwords = os->stack_slots * ORD_BLOCK, tab_dwords = os->n_top_tab * rt::TOP_REC_DWORDS;
+        const int stack_dwords = os->stack_slots * ORD_BLOCK, tab_dwords = os->n_top_tab * (PAIRS ? rt::PAIR_REC_DWORDS : rt::TOP_REC_DWORDS);
         for (int k = threadIdx.x; k < tab_dwords; k += ORD_BLOCK) l[stack_dwords + k] = os->top_tab[k];
         l[threadIdx.x] = (uint32_t)sc.top_end;   // slot 0: where the walk ends
         __syncthreads();
         st.ent = os->ent_ord; st.tris = sc.tris; st.inst = sc.inst; st.planes = sc.planes;
         st.root_link = os->root_link; st.inst_end = os->inst_end;
+        st.pair = os->pair; st.inst_start = os->inst_start;
         st.lds0 = l; st.lds0_addr = (uint32_t)(uintptr_t)l;     // LDS addresses are 32-bit offsets
         st.stack_addr = st.lds0_addr; st.top_addr = st.lds0_addr + 4u * (uint32_t)stack_dwords;
         return st;
@@ -278,15 +280,16 @@ __device__ __forceinline__ void hand_over(const Queues& q, int pass, uint32_t id
 
 // ---- intersect (World.cpp:105-119) ----------------------------------------------------------------------------------
 // (the parameter list is mirrored by IntersectArgs, through which kernarg_read finds cam, g and bt: change both together)
-template <bool FIRST, bool STAGED, bool FOG, int BLOCK = IBLOCK, int MIN_WAVES = 1, bool ORD = false>
+template <bool FIRST, bool STAGED, bool FOG, int BLOCK = IBLOCK, int MIN_WAVES = 1, bool ORD = false, bool PAIRS = false>
 __global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, Cam cam, Cfg g, Batch bt, Queues q, int pass, Debug dbg, Tune tune, OrdScene os) {
     static_assert(!ORD || (!STAGED && !FOG), "the ordered traversal is for scenes read from memory, without fog");
+    static_assert(!PAIRS || ORD, "pair steps are a form of the ordered traversal");
     extern __shared__ float4 smem[];
     const uint32_t n_in = FIRST ? (uint32_t)bt.n_pixels * (uint32_t)(g.S * g.S) : q.counts[pass];
     // a pass with few rays: blocks beyond one smallest reservation per wave leave before they copy the scene
     const uint32_t blocks_used = min((uint32_t)gridDim.x, n_in / ((uint32_t)tune.min_chunk * (BLOCK / 64)) + 1u);
     if (n_in == 0u || blockIdx.x >= blocks_used || cancelled(bt)) return;
-    const Store st = stage_scene<STAGED, ORD ? BLOCK : 0>(sc, smem, &os);
+    const Store st = stage_scene<STAGED, ORD ? BLOCK : 0, PAIRS>(sc, smem, &os);
     const int qin = (pass + 1) & 1;
     // Range r of the queue is every NCUR-th stripe of STRIPE positions, starting with stripe r: all ranges move through
     // the queue side by side, so the grid still works on one neighbourhood of the image at a time.  A wave starts on the
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, C
                     if (walker_is_idle(w) && o < mine_end && idx < n_in) {
                         Ray ray; Rng rng; uint32_t slot, depth;
                         if (fetch_ray<true>(cam_now, g_now, bt_now, q, qin, dbg, idx, ray, rng, slot, depth, FOG)) {
-                            if constexpr (ORD) walker_start_ord<CULL, BLOCK>(sc, st, w, ray, rng); else walker_start<CULL>(sc, st, w, ray, rng);
+                            if constexpr (PAIRS) walker_start_pairs<CULL, BLOCK>(sc, st, w, ray, rng); else if constexpr (ORD) walker_start_ord<CULL, BLOCK>(sc, st, w, ray, rng); else walker_start<CULL>(sc, st, w, ray, rng);
                             const uint32_t tagged = RELOAD && w.usable ? idx | IDX_USABLE : idx;
                             if constexpr (LEAN) my_slot[lane_now()] = tagged; else my_idx = tagged;
                             if (!FOG && sc.has_ref && !w.usable && !ray_monotone(ray)) { hand_over(q, pass, idx); walker_idle(sc, w); }
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, C
                 } else if (walker_is_idle(w) && o < mine_end && idx < n_in) {
                     Ray ray; Rng rng; uint32_t slot, depth;
                     if (fetch_ray<false>(cam, g, bt, q, qin, dbg, idx, ray, rng, slot, depth, FOG)) {
-                        if constexpr (ORD) walker_start_ord<CULL, BLOCK>(sc, st, w, ray, rng); else walker_start<CULL>(sc, st, w, ray, rng);
+                        if constexpr (PAIRS) walker_start_pairs<CULL, BLOCK>(sc, st, w, ray, rng); else if constexpr (ORD) walker_start_ord<CULL, BLOCK>(sc, st, w, ray, rng); else walker_start<CULL>(sc, st, w, ray, rng);
                         const uint32_t tagged = RELOAD && w.usable ? idx | IDX_USABLE : idx;
                         if constexpr (LEAN) my_slot[lane_now()] = tagged; else my_idx = tagged;
                         if (!FOG && sc.has_ref && !w.usable && !ray_monotone(ray)) { hand_over(q, pass, idx); walker_idle(sc, w); }
@@ -402,7 +405,7 @@ __global__ __launch_bounds__(BLOCK, MIN_WAVES) void intersect_kernel(Scene sc, C
         // per SIMD was measured on both kinds of scene and gained nothing: 256-thread blocks on the 100 000-primitive
         // scene 92.9 against 92.3 ms; 640-thread blocks with the scene in LDS lose a fifth, their ten waves do not spread
         // evenly over four SIMDs.)
-        const int ended = walk_round<STAGED, FOG, RELOAD, FIRST, ORD ? BLOCK : 0>(sc, st, w, tune.quorum, tune.prim_quorum, tune.finish_quorum, prof, n_box, q.a[qin], q.b[qin], my_idx, q.hit, my_slot);
+        const int ended = walk_round<STAGED, FOG, RELOAD, FIRST, ORD ? BLOCK : 0, PAIRS>(sc, st, w, tune.quorum, tune.prim_quorum, tune.finish_quorum, prof, n_box, q.a[qin], q.b[qin], my_idx, q.hit, my_slot);
         if (ended == WALK_DONE) {
             // (the lean walker has written the barycentrics of its winning triangle already)
             if constexpr (LEAN) *reinterpret_cast<float2*>(q.hit + (my_slot[lane_now()] & IDX_MASK)) = make_float2(w.c.dist, __int_as_float(w.c.best));
@@ -442,6 +445,7 @@ __global__ __launch_bounds__(256) void exceptions_kernel(Scene sc_ref, Cam cam, 
     Store st;
     st.ent = sc_ref.ent; st.tris = sc_ref.tris; st.inst = sc_ref.inst; st.planes = sc_ref.planes;
     st.lds0 = nullptr; st.lds0_addr = 0; st.top_addr = 0; st.stack_addr = 0; st.root_link = 0; st.inst_end = nullptr;
+    st.pair = nullptr; st.inst_start = nullptr;
     const int qin = (pass + 1) & 1;
     for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {   // (the same for a whole block)
         const uint32_t k = base + threadIdx.x;
@@ -650,6 +654,7 @@ __global__ __launch_bounds__(256) void trace_kernel(Scene sc, Scene sc_ref, int 
     Store st;
     st.ent = sc.ent; st.tris = sc.tris; st.inst = sc.inst; st.planes = sc.planes;
     st.lds0 = nullptr; st.lds0_addr = 0; st.top_addr = 0; st.stack_addr = 0; st.root_link = 0; st.inst_end = nullptr;
+    st.pair = nullptr; st.inst_start = nullptr;
     Walker w;
     walker_idle(sc, w);
     Ray r;
@@ -906,7 +911,8 @@ void launch_intersect(rt_engine* e, hipStream_t st, const Cfg& g, const Batch& b
     if (e->ord_bytes && !e->staged_bytes && !fog) {
         // a scene read from memory: near child first, the far one on a stack in LDS, the tree's upper levels in LDS too
         // (rt_device.h, "ordered traversal"); one 1024-thread block per CU owns the CU's LDS
-        hipLaunchKernelGGL((intersect_kernel<FIRST, false, false, OBLOCK, 1, true>), dim3(e->n_cus), dim3(OBLOCK), e->ord_bytes, st, e->sc, e->cam, g, bt, q, pass, e->dbg, tune, e->os);
+        if (e->os.pairs) hipLaunchKernelGGL((intersect_kernel<FIRST, false, false, OBLOCK, 1, true, true>), dim3(e->n_cus), dim3(OBLOCK), e->ord_bytes, st, e->sc, e->cam, g, bt, q, pass, e->dbg, tune, e->os);
+        else hipLaunchKernelGGL((intersect_kernel<FIRST, false, false, OBLOCK, 1, true>), dim3(e->n_cus), dim3(OBLOCK), e->ord_bytes, st, e->sc, e->cam, g, bt, q, pass, e->dbg, tune, e->os);
         return;
     }
     if (e->staged_bytes) { if (fog) RT_LAUNCH_INTERSECT(true, true, e->staged_bytes); else RT_LAUNCH_INTERSECT(true, false, e->staged_bytes); }
@@ -1051,6 +1057,8 @@ int init_engine(rt_engine* e, const rt_config* cfg) {
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<true, true, false, 768, 6>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<true, false, false, OBLOCK, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_ORD_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<false, false, false, OBLOCK, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_ORD_BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<true, false, false, OBLOCK, 1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_ORD_BYTES));
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<false, false, false, OBLOCK, 1, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_ORD_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&intersect_kernel<false, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, MAX_STAGED_BYTES));
 #ifdef RT_PROFILE
@@ -1318,6 +1326,76 @@ static int rt_engine_set_scene_impl(rt_engine* e, const rt_scene* s) {
         e->os.ent_ord = d_ord; e->os.top_tab = d_tab; e->os.inst_end = d_end;
         e->os.n_top_tab = (int)table.size(); e->os.stack_slots = L.stack_need; e->os.root_link = link_of(0);
         e->ord_bytes = stack_bytes + tab.size() * 4;
+        // Pair steps (rt_device.h, "pair steps"; records: rt_flat.h): in place of the above unless switched off
+        if (!(e->cfg.flags & RT_FLAG_NO_PAIRS)) {
+            auto skip_of = [&](size_t i) { return (size_t)rt::bits_i(L.ent_lo[i].w); };
+            auto has_pair = [&](size_t i) { return is_plain_inner(i) && L.ent_right[i] >= 0 && is_plain_inner(i + 1) && is_plain_inner((size_t)L.ent_right[i]); };
+            // a node whose children are leaves (no instance, no box among them): its leaves are chained, the node is skipped
+            auto leaf_list = [&](size_t i) {
+                if (!is_plain_inner(i) || L.ent_entry_box[i]) return false;
+                for (size_t c = i + 1; c < skip_of(i); c++) { const int k = rt::bits_i(L.ent_hi[c].w); if (k < rt::ENT_SPHERE || k > rt::ENT_TRI) return false; }
+                return skip_of(i) > i + 1;
+            };
+            // the table in LDS: whole levels of nodes that have records, from the root down
+            std::vector<int32_t> ptable, plevel;
+            if (has_pair(0)) plevel.push_back(0);
+            const size_t pmax = std::min<size_t>(((size_t)MAX_ORD_BYTES - stack_bytes) / (rt::PAIR_REC_DWORDS * 4), (size_t)rt::LINK_INDEX);
+            while (!plevel.empty() && ptable.size() + plevel.size() <= pmax) {
+                ptable.insert(ptable.end(), plevel.begin(), plevel.end());
+                std::vector<int32_t> next;
+                for (int32_t i : plevel)
+                    for (int32_t c : {i + 1, L.ent_right[i]})
+                        if (has_pair((size_t)c)) next.push_back(c);
+                plevel.swap(next);
+            }
+            std::vector<int32_t> prec(n, -1);
+            for (size_t k = 0; k < ptable.size(); k++) prec[ptable[k]] = (int32_t)k;
+            auto pair_link = [&](size_t i) { return rt::LINK_PAIR | (prec[i] >= 0 ? (rt::LINK_LDS | (uint32_t)prec[i]) : (uint32_t)i); };
+            // where a step goes for a child: its record; its first leaf, when it is a node of chained leaves; or its entry
+            auto child_link = [&](size_t c) { return has_pair(c) ? pair_link(c) : (leaf_list(c) ? (uint32_t)c + 1u : (uint32_t)c); };
+            auto never_less = [](float rho) { uint32_t b = (uint32_t)rt::bits_i(rho); if (b == 0x7F800000u) b = 0x7FC00000u; return b; };   // +inf: a NaN, which culls nothing
+            std::vector<rt::F4> ent2(inter);
+            std::vector<rt::F4> pairs(n * 4, rt::F4{0, 0, 0, 0});
+            for (size_t i = 0; i < n; i++) {
+                const int kind = rt::bits_i(L.ent_hi[i].w);
+                if (kind == rt::ENT_INNER) {
+                    const uint32_t second = L.ent_right[i] < 0 || leaf_list(i) ? rt::LINK_NONE : (uint32_t)L.ent_right[i];
+                    if (is_plain_inner(i)) ent2[2 * i + 1].z = rt::bits_f((int32_t)(has_pair(i) ? pair_link(i) : second));
+                    else ent2[2 * i + 1].w = rt::bits_f((int32_t)second);      // INNER_INV: kind in dword 6, the link in dword 7
+                    if (leaf_list(i))
+                        for (size_t c = i + 1; c + 1 < skip_of(i); c++) ent2[2 * c + 1].w = rt::bits_f((int32_t)((uint32_t)rt::bits_i(ent2[2 * c + 1].w) | rt::LEAF_MORE));
+                }
+                if (has_pair(i)) {
+                    const size_t a = i + 1, b = (size_t)L.ent_right[i];
+                    const rt::F4 a0 = inter[2 * a], a1 = inter[2 * a + 1], b0 = inter[2 * b], b1 = inter[2 * b + 1];
+                    pairs[4 * i + 0] = a0;
+                    pairs[4 * i + 1] = {a1.x, a1.y, b0.x, b0.y};
+                    pairs[4 * i + 2] = {b0.z, b0.w, b1.x, b1.y};
+                    pairs[4 * i + 3] = {rt::bits_f((int32_t)child_link(a)), rt::bits_f((int32_t)child_link(b)), rt::bits_f((int32_t)never_less(a1.w)), rt::bits_f((int32_t)never_less(b1.w))};
+                }
+            }
+            // (leaf entries: dword 7 of a sphere or cube holds its rank, of a triangle its instance; neither reaches 2^31)
+            std::vector<rt::F4> ptab(ptable.size() * 4);
+            for (size_t k = 0; k < ptable.size(); k++) memcpy(&ptab[4 * k], &pairs[4 * (size_t)ptable[k]], 64);
+            std::vector<uint32_t> inst_start(std::max<size_t>(1, L.inst.size() / rt::RT_INST_F4), 0u);
+            for (size_t k = 0; k + rt::RT_INST_F4 <= L.inst.size(); k += rt::RT_INST_F4) {
+                const size_t b = (size_t)rt::bits_i(L.inst[k + 2].z);
+                inst_start[k / rt::RT_INST_F4] = has_pair(b) ? pair_link(b) : (uint32_t)b;
+            }
+            float4 *d_ent2, *d_pairs; uint32_t *d_ptab, *d_start;
+            if (int rc = upload(&d_ent2, ent2.data(), ent2.size() * 16)) return rc;
+            e->scene_allocs.push_back(d_ent2);
+            if (int rc = upload(&d_pairs, pairs.data(), pairs.size() * 16)) return rc;
+            e->scene_allocs.push_back(d_pairs);
+            if (int rc = upload(&d_ptab, ptab.data(), ptab.size() * 16)) return rc;
+            e->scene_allocs.push_back(d_ptab);
+            if (int rc = upload(&d_start, inst_start.data(), inst_start.size() * 4)) return rc;
+            e->scene_allocs.push_back(d_start);
+            e->os.ent_ord = d_ent2; e->os.top_tab = d_ptab; e->os.pair = d_pairs; e->os.inst_start = d_start;
+            e->os.n_top_tab = (int)ptable.size(); e->os.root_link = has_pair(0) ? pair_link(0) : 0u;
+            e->os.pairs = 1;
+            e->ord_bytes = stack_bytes + ptab.size() * 16;
+        }
     }
     e->sc = sc;
     e->have_scene = true;

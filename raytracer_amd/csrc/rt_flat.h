@@ -71,6 +71,14 @@ constexpr uint32_t ENTRY_BOX_MARK = 0x7FC00010u;
 
 constexpr uint32_t LINK_LDS = 1u << 26, LINK_INDEX = LINK_LDS - 1u, LINK_NONE = LINK_INDEX;
 constexpr int TOP_REC_DWORDS = 10;
+// Pair records (rt_device.h, "pair steps"): an inner node both of whose children have boxes, as the two children's boxes
+// side by side, 16 dwords:  A.min.x A.max.x A.min.y A.max.y | A.min.z A.max.z B.min.x B.max.x | B.min.y B.max.y B.min.z
+// B.max.z | link of A, link of B, rho of A, rho of B.   A link with LINK_PAIR set names a pair record (LINK_LDS: its place
+// in the table in LDS; otherwise the node's entry index, which also indexes the array of records); without it, an entry.
+// In the entries that go with pair records a leaf whose sibling leaf follows at the next index has LEAF_MORE set in
+// dword 7, and an inner entry that has a pair record names it in dword 6 (where the others name their second child).
+constexpr uint32_t LINK_PAIR = 1u << 30, LEAF_MORE = 1u << 31;
+constexpr int PAIR_REC_DWORDS = 16;
 
 inline float bits_f(int32_t i) { union { int32_t i; float f; } u; u.i = i; return u.f; }
 inline int32_t bits_i(float f) { union { int32_t i; float f; } u; u.f = f; return u.i; }

@@ -20,6 +20,7 @@ FLAG_NO_CULL = 1                # RT_FLAG_NO_CULL
 FLAG_NO_LDS = 2                 # RT_FLAG_NO_LDS
 FLAG_NO_ORDER = 4               # RT_FLAG_NO_ORDER
 FLAG_NO_REGROUP = 8             # RT_FLAG_NO_REGROUP
+FLAG_NO_PAIRS = 16              # RT_FLAG_NO_PAIRS
 
 f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
