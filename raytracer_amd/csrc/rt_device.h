@@ -1068,12 +1068,13 @@ __device__ __forceinline__ void box_steps_ord(const Store& st, Walker& w, int qu
 // an entry) and every ray outside the reciprocal path waits for walker_special.
 // Registers: the record occupies v16..v31 (four 16-byte loads); an entry its first half, dword 6 in v22, dword 7 in v23.
 template <int BLOCK>
-__device__ __forceinline__ void box_steps_pairs(const Store& st, Walker& w, int quorum, uint32_t& n_box) {
+__device__ __forceinline__ void box_steps_pairs(const Store& st, Walker& w, int quorum, Prof& prof, uint32_t& n_box) {
     const unsigned long long px = __ballot(w.p3.x >= 0), py = __ballot(w.p3.y >= 0), pz = __ballot(w.p4.x >= 0);
     const unsigned long long usable = __ballot(w.usable);
     unsigned long long m, m2, m3, m4, mall, saved, mhit, mpop, ma, mb;
     int n_pair;
     uint32_t nb = 0;
+    RT_PROF(uint32_t box_iters = 0; uint32_t box_lanes = 0;)
     const float4* base = st.ent;
     const float4* pbase = st.pair;
     const uint32_t ldsbase = st.top_addr;
@@ -1090,6 +1091,7 @@ __device__ __forceinline__ void box_steps_pairs(const Store& st, Walker& w, int 
              "s_or_b64 %[mall], %[m], %[m2]\n\t"
              "s_cmp_eq_u64 %[mall], 0\n\t"
              "s_cbranch_scc1 2f\n\t"
+             RT_BOX_COUNT
              "s_mov_b64 %[mpop], 0\n\t"
              "s_cmp_eq_u64 %[m], 0\n\t"
              "s_cbranch_scc1 3f\n\t"
@@ -1279,12 +1281,13 @@ __device__ __forceinline__ void box_steps_pairs(const Store& st, Walker& w, int 
                [g45] "+{v[26:27]}"(w.g45), [lk] "+{v[28:29]}"(w.lk), [rh] "+{v[30:31]}"(w.rh), [i] "+v"(w.i), [f0] "+v"(w.f0),
                [f1] "+v"(w.f1), [f2] "+v"(w.f2), [cnt] "+v"(w.cnt), [m] "=&s"(m), [m2] "=&s"(m2), [m3] "=&s"(m3),
                [mall] "=&s"(mall), [saved] "=&s"(saved), [cntS] "=&s"(n_pair), [m4] "=&s"(m4), [nbox] "+s"(nb),
-               [mhit] "=&s"(mhit), [mpop] "=&s"(mpop), [ma] "=&s"(ma), [mb] "=&s"(mb), [sp] "+v"(w.sp)
+               [mhit] "=&s"(mhit), [mpop] "=&s"(mpop), [ma] "=&s"(ma), [mb] "=&s"(mb), [sp] "+v"(w.sp) RT_BOX_COUNT_OPERANDS
              : [p0] "v"(w.p0), [p1] "v"(w.p1), [p2] "v"(w.p2), [p3] "v"(w.p3), [p4] "v"(w.p4), [px] "s"(px), [py] "s"(py),
                [pz] "s"(pz), [base] "s"(base), [pbase] "s"(pbase), [usable] "s"(usable), [quorum] "s"(quorum), [ck] "v"(w.cull_k), [cbase] "v"(w.cull_base),
                [ldsbase] "s"(ldsbase), [stride] "n"(BLOCK * 4)
              : "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", "v10", "v11", "v12", "v13", "v14", "v15", "vcc", "scc", "memory");
     n_box += nb;
+    RT_PROF(prof.box_iters += box_iters; prof.box_lanes += box_lanes;)
 }
 // What the lane stands on, for the code around the loop: a pair record reads as an inner entry (kind 0), an entry as itself
 __device__ __forceinline__ void pairs_sync_kind(Walker& w) {
@@ -1519,7 +1522,7 @@ __device__ __forceinline__ int walk_round(const Scene& sc, const Store& st, Walk
     prim_quorum = max(1, min(prim_quorum, (busy + 1) >> 1));
     finish_quorum = max(1, min(finish_quorum, (busy + 1) >> 1));
     constexpr bool CULL = !LDS && !FOG;   // see "distance culling": large scenes, and never when traversal draws random numbers
-    if constexpr (PAIRS) { box_steps_pairs<ORD>(st, w, quorum, n_box); pairs_sync_kind(w); }
+    if constexpr (PAIRS) { box_steps_pairs<ORD>(st, w, quorum, prof, n_box); pairs_sync_kind(w); }
     else if constexpr (ORD != 0) box_steps_ord<ORD>(st, w, quorum, n_box); else box_steps<LDS>(st, w, quorum, prof, n_box);
     RT_PROF(unsigned long long t1 = __builtin_readcyclecounter(); prof.box += t1 - t0;)
     for (;;) {

@@ -759,8 +759,10 @@ def test_random_scenes_bit_exact(rt, orc, assets, seed, monkeypatch):
     # reference's order without one, as scenes with fog are always walked)
     E = rt.engine
     # (FLAG_NO_REGROUP: the reference's hierarchy above the lowest nodes of the meshes' trees instead of the engine's own)
+    # (FLAG_NO_PAIRS: one box per step of the near-side-first walk instead of a node's two children per step)
     for flags in (E.FLAG_NO_LDS, E.FLAG_NO_LDS | E.FLAG_NO_CULL, E.FLAG_NO_LDS | E.FLAG_NO_ORDER, E.FLAG_NO_LDS | E.FLAG_NO_ORDER | E.FLAG_NO_CULL, 0,
-                  E.FLAG_NO_REGROUP, E.FLAG_NO_REGROUP | E.FLAG_NO_LDS):
+                  E.FLAG_NO_REGROUP, E.FLAG_NO_REGROUP | E.FLAG_NO_LDS, E.FLAG_NO_LDS | E.FLAG_NO_PAIRS, E.FLAG_NO_LDS | E.FLAG_NO_PAIRS | E.FLAG_NO_CULL,
+                  E.FLAG_NO_LDS | E.FLAG_NO_PAIRS | E.FLAG_NO_REGROUP):
         m = make_engine(rt, scene, W, H, S, B, cam, flags=flags)
         m.keep_samples(True)
         frame_m = m.render_frame(seed)
@@ -811,7 +813,8 @@ def test_large_mesh_read_from_memory(rt, orc, assets):
     assert (ref["primary_id"] == 0).mean() > 0.08                       # the sheet is in view (much of it cut out by its texture)
     E = rt.engine
     counts = {}
-    for flags in (0, E.FLAG_NO_REGROUP, E.FLAG_NO_ORDER, E.FLAG_NO_CULL, E.FLAG_NO_REGROUP | E.FLAG_NO_ORDER | E.FLAG_NO_CULL):
+    for flags in (0, E.FLAG_NO_REGROUP, E.FLAG_NO_ORDER, E.FLAG_NO_CULL, E.FLAG_NO_REGROUP | E.FLAG_NO_ORDER | E.FLAG_NO_CULL,
+                  E.FLAG_NO_PAIRS, E.FLAG_NO_PAIRS | E.FLAG_NO_REGROUP, E.FLAG_NO_PAIRS | E.FLAG_NO_CULL):
         e = make_engine(rt, scene, W, H, S, B, cam, flags=flags)
         e.keep_samples(True)
         frame = e.render_frame(21)
@@ -943,6 +946,14 @@ def test_distance_culling_changes_nothing(rt, orc, assets):
     n_ref = e2.stats()["box_tests"]
     assert_bits(a, a2, "frame through the regrouped and through the reference's hierarchy")
     assert 0 < n_cull < n_unordered < n_all <= n_ref and n_unordered < 0.7 * n_ref, (n_cull, n_unordered, n_all, n_ref)
+    # ... and near side first one box per step (e above tests a node's two children per step)
+    e3 = make_engine(rt, scene, 256, 256, 2, 4, cam, flags=rt.engine.FLAG_NO_PAIRS)
+    hit3, rec3 = e3.trace(o, d)
+    assert_bits(hit3, hit, "ids, one box per step")
+    assert_bits(rec3, rec, "hit records, one box per step")
+    assert_bits(e3.ray_color(o, d, 4, keys), col, "radiance, one box per step")
+    assert_bits(e3.render_frame(5), a, "frame, one box per step")
+    assert 0 < e3.stats()["box_tests"] < n_unordered
     print(f"slab tests per frame: {n_ref} in the reference's hierarchy, {n_all} regrouped, {n_unordered} culled in the stored child order, {n_cull} culled near side first")
 
 
