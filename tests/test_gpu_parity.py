@@ -683,10 +683,13 @@ def test_rays_the_regrouped_hierarchy_is_not_proven_for(rt, oracle_default, gpu_
     assert (got["primary_id"].reshape(H, W, S * S)[:, W // 2, 0] == 2).sum() > 5      # (sample 0 of that column: the trunk)
 
 
-@pytest.mark.parametrize("case", ["single_sphere_no_plane", "single_fog", "one_pixel", "no_bounces", "max_bounces"])
+@pytest.mark.parametrize("case", ["single_sphere_no_plane", "single_fog", "one_pixel", "no_bounces", "max_bounces", "two_objects", "three_objects", "five_objects"])
 def test_degenerate_scenes_and_sizes(rt, orc, assets, case):
     """the small ends of the input space: a BVH whose root has the same object as both children (Object.cpp:198-200), a
-    scene without planes, a 1 x 1 frame, zero bounces, the largest bounce count the engine accepts"""
+    scene without planes, a 1 x 1 frame, zero bounces, the largest bounce count the engine accepts; trees of two, three
+    and five objects (a root whose children are leaves; a root with one leaf and one node; the smallest tree in which a
+    node's two children both have boxes) — each also through the kernels that read the scene from memory, whose walk
+    starts at the root's children"""
     tex = [[0, .7, .6, .5, 0, 0, 0], [1, 1, 1, 1, .1, .4, .2]]
     mat = [[1, 0, 0, 0, 0], [2, 1, 0, 0, 0], [3, 0, 0, 0, 0]]
     obj = np.zeros((3, 10), np.float32)
@@ -705,6 +708,14 @@ def test_degenerate_scenes_and_sizes(rt, orc, assets, case):
         B = 0
     elif case == "max_bounces":
         B, W, H = 32, 48, 27
+    elif case in ("two_objects", "three_objects", "five_objects"):
+        more = np.zeros((5, 10), np.float32)
+        more[0] = obj[0]
+        more[1] = obj[1]
+        more[2] = [0, -1.5, 1.0, 4.0, 1.0, 0, 0, 0, 0, 1]
+        more[3] = [1, 3.5, 0.0, 5.0, 5.0, 2.5, 7.0, 0, 0, 0]
+        more[4] = [0, 0.0, 6.0, 9.0, 3.0, 0, 0, 0, 0, 1]
+        obj = more[:{"two_objects": 2, "three_objects": 3, "five_objects": 5}[case]]
     args = (tex, mat, obj, plane, None, None, assets["sky"], 77)
     scene = build_table_scene(rt.Scene(), *args)
     osc = build_table_scene(orc.Scene(orc.MATH_PORTABLE), *args)
@@ -719,6 +730,16 @@ def test_degenerate_scenes_and_sizes(rt, orc, assets, case):
     assert_bits(got["rng_draws"], ref["rng_draws"], case + ": RNG draws")
     assert_bits(got["radiance"], ref["radiance"], case + ": radiance")
     assert_bits(frame, ref["rgba"], case + ": frame")
+    E = rt.engine
+    for flags in (E.FLAG_NO_LDS, E.FLAG_NO_LDS | E.FLAG_NO_PAIRS, E.FLAG_NO_LDS | E.FLAG_NO_ORDER, E.FLAG_NO_LDS | E.FLAG_NO_CULL):
+        m = make_engine(rt, scene, W, H, S, B, cam, flags=flags)
+        m.keep_samples(True)
+        frame_m = m.render_frame(9)
+        got_m = m.read_samples()
+        for name in ("primary_id", "primary_t", "rng_draws", "radiance"):
+            assert_bits(got_m[name], ref[name], f"{case} read from memory (flags {flags}): {name}")
+        assert_bits(frame_m, ref["rgba"], f"{case} read from memory (flags {flags}): frame")
+        m.close()
 
 
 # RT_EXTRA_SEEDS="a-b" adds the seeds a..b-1 for a wider sweep than the suite's eight scenes
