@@ -1495,7 +1495,8 @@ __device__ __forceinline__ int walker_special(const Scene& sc, const Store& st, 
             const bool hit = entry_box || box_hit(mk(w.e01.x, w.e23.x, w.e45.x), mk(w.e01.y, w.e23.y, w.e45.y), walker_ray(w));
             const uint32_t second = kind == rt::ENT_INNER ? w.sk : __float_as_uint(w.rho);
             const uint32_t first = ((uint32_t)w.i & rt::LINK_LDS) ? w.eleft : (uint32_t)w.i + 1u;
-            if (PAIRS && kind == rt::ENT_INNER && (second & rt::LINK_PAIR)) w.i = hit ? (int)second : (int)ord_pop(st, w, ORD * 4);   // its record takes over
+            if (PAIRS && kind == rt::ENT_INNER && (second & rt::ENTRY_HAS_PAIR))   // its record takes over
+                w.i = hit ? (int)(rt::LINK_PAIR | (second & (rt::LINK_LDS | rt::LINK_INDEX))) : (int)ord_pop(st, w, ORD * 4);
             else {
                 if (hit && second != rt::LINK_NONE) ord_push(st, w, second, ORD * 4);
                 w.i = hit ? (int)first : (int)ord_pop(st, w, ORD * 4);

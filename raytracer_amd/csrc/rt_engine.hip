@@ -1360,7 +1360,7 @@ static int rt_engine_set_scene_impl(rt_engine* e, const rt_scene* s) {
                 const int kind = rt::bits_i(L.ent_hi[i].w);
                 if (kind == rt::ENT_INNER) {
                     const uint32_t second = L.ent_right[i] < 0 || leaf_list(i) ? rt::LINK_NONE : (uint32_t)L.ent_right[i];
-                    if (is_plain_inner(i)) ent2[2 * i + 1].z = rt::bits_f((int32_t)(has_pair(i) ? pair_link(i) : second));
+                    if (is_plain_inner(i)) ent2[2 * i + 1].z = rt::bits_f((int32_t)(has_pair(i) ? (pair_link(i) & ~rt::LINK_PAIR) | rt::ENTRY_HAS_PAIR : second));
                     else ent2[2 * i + 1].w = rt::bits_f((int32_t)second);      // INNER_INV: kind in dword 6, the link in dword 7
                     if (leaf_list(i))
                         for (size_t c = i + 1; c + 1 < skip_of(i); c++) ent2[2 * c + 1].w = rt::bits_f((int32_t)((uint32_t)rt::bits_i(ent2[2 * c + 1].w) | rt::LEAF_MORE));

@@ -76,8 +76,10 @@ constexpr int TOP_REC_DWORDS = 10;
 // B.max.z | link of A, link of B, rho of A, rho of B.   A link with LINK_PAIR set names a pair record (LINK_LDS: its place
 // in the table in LDS; otherwise the node's entry index, which also indexes the array of records); without it, an entry.
 // In the entries that go with pair records a leaf whose sibling leaf follows at the next index has LEAF_MORE set in
-// dword 7, and an inner entry that has a pair record names it in dword 6 (where the others name their second child).
-constexpr uint32_t LINK_PAIR = 1u << 30, LEAF_MORE = 1u << 31;
+// dword 7, and an inner entry that has a pair record names it in dword 6 (where the others name their second child):
+// ENTRY_HAS_PAIR | the record's place (LINK_LDS | k, or the entry's own index) — inside the 28-bit payload, so that the
+// entry's kind still reads as INNER (LINK_PAIR itself would read as a leaf's kind there).
+constexpr uint32_t LINK_PAIR = 1u << 30, LEAF_MORE = 1u << 31, ENTRY_HAS_PAIR = 1u << 27;
 constexpr int PAIR_REC_DWORDS = 16;
 
 inline float bits_f(int32_t i) { union { int32_t i; float f; } u; u.i = i; return u.f; }

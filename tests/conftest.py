@@ -107,16 +107,18 @@ def synthetic_tables(n):
     return st(n)
 
 
-def random_tables(seed):
+def random_tables(seed, fog=True):
     """a small scene drawn from a seeded generator: every primitive kind, texture kind, material, rotation axis and
-    wrapper, at sizes and places that make them overlap"""
+    wrapper, at sizes and places that make them overlap; fog=False: no fog volumes (scenes with fog are walked in the
+    reference's order by kernels of their own; without it the engine's shortcuts — its own hierarchy over meshes, near
+    side first, culling, pair steps — are what runs), more objects and more meshes instead"""
     r = np.random.default_rng(seed)
     tex = [[0, *r.uniform(0.1, 1.0, 3), 0, 0, 0], [1, *r.uniform(0.1, 1.0, 3), *r.uniform(0.1, 1.0, 3)], [2, 0, 0, 0, 0, 0, 0]]
     mat = [[1, 0, 0, 0, 0], [1, 1, 0, 0, 0], [1, 2, 0, 0, 0], [2, 0, 0, 0, 0], [2, 1, 0, 0, 0], [3, 0, 0, 0, 0], [4, -1, *r.uniform(1.0, 6.0, 3)],
            [0, -1, 0, 0, 0]]
     obj = []
-    for _ in range(int(r.integers(6, 40))):
-        k = int(r.choice([0, 0, 0, 1, 2, 4]))
+    for _ in range(int(r.integers(6, 40)) if fog else int(r.integers(2, 90))):
+        k = int(r.choice([0, 0, 0, 1, 2, 4] if fog else [0, 0, 0, 1, 1, 2]))
         c = r.uniform(-12, 12, 3) * [1, 0.4, 1] + [0, 3, 8]
         m = int(r.integers(0, len(mat)))
         if k == 0:
@@ -129,7 +131,7 @@ def random_tables(seed):
         else:
             obj.append([4, *c, r.uniform(1.0, 5.0), r.uniform(0.02, 0.6), int(r.integers(-1, 3)), r.uniform(0, 360),
                         float(r.choice([0.0, 0.0, r.uniform(-3, 3)])), 5])
-    for _ in range(int(r.integers(0, 3))):   # mesh instances: scale, rotation axis, degrees, offset, offset present, material (image texture)
+    for _ in range(int(r.integers(0, 3)) if fog else int(r.integers(0, 5))):   # mesh instances: scale, rotation axis, degrees, offset, offset present, material (image texture)
         mv = r.uniform(-6, 6, 3) * [1, 0.2, 1] + [0, 2, 6]
         obj.append([3, r.uniform(2, 9), int(r.integers(-1, 3)), r.uniform(0, 360), *mv, int(r.integers(0, 2)), 0, int(r.choice([2, 2, 0, 3]))])
     plane = [[float(r.uniform(-1, 1)), int(r.choice([0, 1, 3, 4]))] for _ in range(int(r.integers(0, 3)))]

@@ -751,10 +751,22 @@ def _extra_seeds():
     return list(range(int(lo), int(hi)))
 
 
+@pytest.mark.parametrize("seed", [111, 222, 333, 444, 555, 666, 777, 888] + _extra_seeds())
+def test_random_scenes_without_fog_bit_exact(rt, orc, assets, seed, monkeypatch):
+    """the same without fog volumes, so that the memory-resident variants below run the engine's own hierarchy over the
+    meshes, the near-side-first walk, culling and pair steps (a scene with fog keeps the reference's order throughout)"""
+    _random_scene_check(rt, orc, assets, seed, monkeypatch, fog=False)
+
+
 @pytest.mark.parametrize("seed", [101, 202, 303, 404, 505, 606, 707, 808] + _extra_seeds())
 def test_random_scenes_bit_exact(rt, orc, assets, seed, monkeypatch):
     """scenes nobody arranged: ids, distances, draw counts, radiance and frame bytes against the oracle, bit for bit"""
-    tex, mat, obj, plane, (pos, look) = random_tables(seed)
+    _random_scene_check(rt, orc, assets, seed, monkeypatch, fog=True)
+
+
+def _random_scene_check(rt, orc, assets, seed, monkeypatch, fog):
+    tex, mat, obj, plane, (pos, look) = random_tables(seed, fog)
+    assert fog or not (obj[:, 0] == 4).any()
     args = (tex, mat, obj, plane, assets["verts"], assets["tex"], assets["sky"], 0xC0FFEE + seed)
     scene = build_table_scene(rt.Scene(), *args)
     osc = build_table_scene(orc.Scene(orc.MATH_PORTABLE), *args)
