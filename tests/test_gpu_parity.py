@@ -806,6 +806,48 @@ def _random_scene_check(rt, orc, assets, seed, monkeypatch, fog):
         m.close()
 
 
+@pytest.mark.parametrize("n_tris", [1, 2, 3, 5, 8])
+def test_tiny_meshes(rt, orc, assets, n_tris):
+    """meshes of one to eight triangles (a tree that is one lowest node; a root whose children are lowest nodes; the
+    smallest trees with nodes above those), twice in a scene with a few spheres, rotated and moved: on-chip and read from
+    memory, through every shortcut, against the oracle bit for bit"""
+    r = np.random.default_rng(1000 + n_tris)
+    tris = []
+    for k in range(n_tris):
+        c = r.uniform([-1, -1, -0.3], [1, 1, 0.3])
+        P = c + r.uniform(-0.8, 0.8, (3, 3))
+        nrm = np.cross(P[1] - P[0], P[2] - P[0])
+        nrm /= np.linalg.norm(nrm)
+        for v in range(3):
+            tris.append([*P[v], *r.uniform(0, 1, 2), *nrm])
+    verts = np.array(tris, np.float32)
+    tex = np.array([[0, 0.8, 0.7, 0.6, 0, 0, 0], [1, 0.9, 0.9, 0.9, 0.2, 0.5, 0.3], [2, 0, 0, 0, 0, 0, 0]], np.float32)
+    mat = np.array([[1, 0, 0, 0, 0], [2, 1, 0, 0, 0], [1, 2, 0, 0, 0]], np.float32)
+    obj = [[3, 6.0, 1, 20.0, -2.5, 3.0, 2.0, 1, 0, 0], [3, 5.0, 0, 75.0, 3.0, 2.5, 4.0, 1, 0, 2]]
+    for _ in range(5):
+        c = r.uniform([-6, 0.5, -1], [6, 6, 9])
+        obj.append([0, *c, r.uniform(0.4, 1.5), 0, 0, 0, 0, int(r.integers(0, 2))])
+    obj = np.array(obj, np.float32)
+    args = (tex, mat, obj, [[0.0, 1]], verts, assets["tex"], assets["sky"], 4242 + n_tris)
+    scene = build_table_scene(rt.Scene(), *args)
+    osc = build_table_scene(orc.Scene(orc.MATH_PORTABLE), *args)
+    W, H, S, B = 96, 54, 2, 4
+    cam = rt.camera_look((0.0, 3.0, -9.0), (0.0, 0.0, 1.0))
+    ref = osc.render(cam, W, H, S, B, 5, threads=8, want=("radiance", "rgba", "rng_draws", "primary_id", "primary_t"))
+    assert ((ref["primary_id"] == 0) | (ref["primary_id"] == 1)).mean() > 0.002         # the meshes are in view
+    E = rt.engine
+    for flags in (0, E.FLAG_NO_REGROUP, E.FLAG_NO_LDS, E.FLAG_NO_LDS | E.FLAG_NO_PAIRS, E.FLAG_NO_LDS | E.FLAG_NO_ORDER, E.FLAG_NO_LDS | E.FLAG_NO_CULL,
+                  E.FLAG_NO_LDS | E.FLAG_NO_REGROUP, E.FLAG_NO_LDS | E.FLAG_NO_REGROUP | E.FLAG_NO_PAIRS):
+        e = make_engine(rt, scene, W, H, S, B, cam, flags=flags)
+        e.keep_samples(True)
+        frame = e.render_frame(5)
+        got = e.read_samples()
+        for name in ("primary_id", "primary_t", "rng_draws", "radiance"):
+            assert_bits(got[name], ref[name], f"{n_tris}-triangle meshes (flags {flags}): {name}")
+        assert_bits(frame, ref["rgba"], f"{n_tris}-triangle meshes (flags {flags}): frame")
+        e.close()
+
+
 def test_large_mesh_read_from_memory(rt, orc, assets):
     """A mesh of 9 800 triangles (a bumpy sheet with the tree's cut-out texture, rotated and moved) among spheres: too large
     for on-chip memory, so the mesh's tree is walked by the kernels of large scenes, regrouped (top-down cuts, then
