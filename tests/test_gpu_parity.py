@@ -683,6 +683,64 @@ def test_rays_the_regrouped_hierarchy_is_not_proven_for(rt, oracle_default, gpu_
     assert (got["primary_id"].reshape(H, W, S * S)[:, W // 2, 0] == 2).sum() > 5      # (sample 0 of that column: the trunk)
 
 
+def test_rays_outside_the_fast_paths(rt, orc, assets):
+    """Rays the shortcuts are not proven for must take the reference's arithmetic as written: origins far outside the
+    scene (beyond the distance up to which a mesh instance's entry box is proven, and beyond the range in which the
+    reciprocal path reproduces division), direction components below 2^-20 or above 2^20 in magnitude, directions that
+    are not of unit length by many orders of magnitude, infinities and NaNs.  Closest hits and radiance against the
+    oracle bit for bit, with the scene on chip and read from memory (near side first, pair steps), regrouped or not.
+    The tree's mesh carries a plain colour here: with its image texture the reference looks the cut-out up outside the
+    image for such rays (texture coordinates computed from a hit point that is off by many units, DataUtility.h:82)."""
+    tex = np.array([[0, 0.8, 0.7, 0.6, 0, 0, 0], [1, 0.9, 0.9, 0.9, 0.2, 0.5, 0.3]], np.float32)
+    mat = np.array([[1, 0, 0, 0, 0], [2, 1, 0, 0, 0]], np.float32)
+    obj = [[3, 10.0, 0, 90.0, 0.0, 5.0, 0.0, 1, 0, 0], [3, 6.0, 1, 30.0, 7.0, 3.0, 5.0, 1, 0, 0]]
+    r = np.random.default_rng(12)
+    for _ in range(9):
+        obj.append([0, *r.uniform([-9, 0.5, -6], [9, 8, 12]), r.uniform(0.5, 2.0), 0, 0, 0, 0, int(r.integers(0, 2))])
+    obj = np.array(obj, np.float32)
+    args = (tex, mat, obj, [[0.0, 1]], assets["verts"], assets["tex"], assets["sky"], 31337)
+    scene = build_table_scene(rt.Scene(), *args)
+    osc = build_table_scene(orc.Scene(orc.MATH_PORTABLE), *args)
+    assert scene.regroup_info()["has_regrouped_layout"] == 1
+    rng = np.random.default_rng(77)
+    n = 4000
+    target = np.array([0, 5, 0], np.float32) + rng.uniform(-3, 3, (n, 3)).astype(np.float32)      # around the first tree
+    u = rng.normal(size=(n, 3))
+    u /= np.linalg.norm(u, axis=1, keepdims=True)
+    dist = np.float32(10.0) ** rng.uniform(1, 13, (n, 1)).astype(np.float32)                      # 10 .. 1e13 units away
+    o = (target - u * dist).astype(np.float32)
+    d = u.astype(np.float32)
+    # a share with one tiny component, a share scaled far off unit length, a few with infinities and NaNs
+    k = n // 4
+    d[:k, rng.integers(0, 3, k)] *= np.float32(1e-9)
+    d[k:2 * k] *= (np.float32(10.0) ** rng.uniform(-12, 12, (k, 1))).astype(np.float32)
+    o[2 * k:2 * k + 40] = rng.uniform(-8, 8, (40, 3)).astype(np.float32)
+    d[2 * k:2 * k + 10, 0] = np.inf
+    d[2 * k + 10:2 * k + 20, 1] = -np.inf
+    d[2 * k + 20:2 * k + 30, 2] = np.nan
+    o[2 * k + 30:2 * k + 40, 1] = np.inf
+    # near origins with ordinary directions beside them, so that waves hold both kinds
+    o[3 * k:] = rng.uniform([-9, 0.5, -12], [9, 10, 9], (n - 3 * k, 3)).astype(np.float32)
+    keys = (np.arange(n, dtype=np.uint64) * 2246822519 % (1 << 32)).astype(np.uint32)
+    h_or, r_or = osc.trace(o, d)
+    # (radiance only for rays whose direction is of unit length: the reference's sky lookup is not clamped and indexes
+    # outside its image for any other, World.cpp:173-193)
+    fin = np.isfinite(o).all(axis=1) & np.isfinite(d).all(axis=1)
+    fin[k:2 * k] = False
+    c_or = osc.ray_color(o[fin], d[fin], 3, keys[fin])
+    assert (h_or >= 0).sum() > 500 and (h_or[:3 * k] == 0).sum() > 50        # far rays do meet the tree
+    cam = rt.camera_look(CAM_POS, CAM_LOOK)
+    E = rt.engine
+    for flags in (0, E.FLAG_NO_REGROUP, E.FLAG_NO_LDS, E.FLAG_NO_LDS | E.FLAG_NO_PAIRS, E.FLAG_NO_LDS | E.FLAG_NO_REGROUP, E.FLAG_NO_LDS | E.FLAG_NO_ORDER):
+        e = make_engine(rt, scene, 64, 64, 1, 3, cam, flags=flags)
+        hit, rec = e.trace(o, d)
+        assert_bits(hit, h_or, f"ids of rays outside the fast paths (flags {flags})")
+        assert_bits(rec[:, 0], r_or[:, 0], f"their distances (flags {flags})")
+        assert_bits(e.ray_color(o[fin], d[fin], 3, keys[fin]), c_or, f"their radiance (flags {flags})")
+        e.ray_color(o[~fin], d[~fin], 3, keys[~fin])          # the others: no fault, whatever the colour
+        e.close()
+
+
 @pytest.mark.parametrize("case", ["single_sphere_no_plane", "single_fog", "one_pixel", "no_bounces", "max_bounces", "two_objects", "three_objects", "five_objects"])
 def test_degenerate_scenes_and_sizes(rt, orc, assets, case):
     """the small ends of the input space: a BVH whose root has the same object as both children (Object.cpp:198-200), a
