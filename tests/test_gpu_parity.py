@@ -663,6 +663,11 @@ def test_rays_the_regrouped_hierarchy_is_not_proven_for(rt, oracle_default, gpu_
     col = e.ray_color(o, d, 4, keys)
     assert_bits(col, oracle_default.ray_color(o, d, 4, keys), "radiance of such rays vs the oracle")
     assert_bits(col, e0.ray_color(o, d, 4, keys), "radiance vs the engine on the reference's hierarchy")
+    # the same through the kernels that read the scene from memory (near side first: pair steps, one box per step)
+    for flags in (rt.engine.FLAG_NO_LDS, rt.engine.FLAG_NO_LDS | rt.engine.FLAG_NO_PAIRS, rt.engine.FLAG_NO_LDS | rt.engine.FLAG_NO_ORDER):
+        em = make_engine(rt, gpu_default, 128, 128, 1, 4, flags=flags)
+        assert_bits(em.ray_color(o, d, 4, keys), col, f"radiance of such rays, scene read from memory (flags {flags})")
+        em.close()
     # a frame through both hierarchies, and the work the regrouped one saves
     a, a0 = e.render_frame(3), e0.render_frame(3)
     assert_bits(a, a0, "frame through the regrouped and through the reference's hierarchy")
