@@ -686,6 +686,9 @@ def test_rays_the_regrouped_hierarchy_is_not_proven_for(rt, oracle_default, gpu_
         assert_bits(got[name], ref[name], f"frame without lens offsets: {name}")
     assert_bits(frame, ref["rgba"], "frame without lens offsets")
     assert (got["primary_id"].reshape(H, W, S * S)[:, W // 2, 0] == 2).sum() > 5      # (sample 0 of that column: the trunk)
+    pm = make_engine(rt, gpu_default, W, H, S, B, cam, dof_intensity=0.0, flags=rt.engine.FLAG_NO_LDS)
+    assert_bits(pm.render_frame(11), ref["rgba"], "frame without lens offsets, scene read from memory")
+    pm.close()
 
 
 def test_rays_outside_the_fast_paths(rt, orc, assets):
@@ -1241,3 +1244,10 @@ def test_c3_full_frame_properties(rt, golden, c3_scene):
     assert_bits(a0, a, "C3 frame without distance culling")
     print(f"C3 slab tests per ray: {n_cull / rays:.1f} executed with culling, {n_all / rays:.1f} without")
     assert n_cull < n_all
+    e0.close()
+    # ... and one box per step instead of a node's two children (a quarter of the frame's height is enough here)
+    e1 = make_engine(rt, scene, W, H, S, B, cam, flags=rt.engine.FLAG_NO_PAIRS)
+    e1.set_window((0, 810, W, 1350))
+    a1 = e1.render_frame(seed)
+    assert_bits(a1[810:1350], a[810:1350], "C3 rows 810-1349, one box per step")
+    e1.close()
