@@ -872,6 +872,47 @@ def _random_scene_check(rt, orc, assets, seed, monkeypatch, fog):
         m.close()
 
 
+@pytest.mark.parametrize("seed", [1, 2])
+def test_random_large_scenes_read_from_memory(rt, orc, assets, seed):
+    """6 000 spheres (a fifth of them with negative radius: boxes with min > max all over the tree) and cubes and two
+    meshes: a top-level tree deeper than the table of upper levels that the blocks keep on chip, so the walk crosses from
+    table records to records in memory and, at every box with min > max, from records to entries and back.  Ids,
+    distances, draw counts, radiance and frame against the oracle bit for bit, through the engine's shortcuts."""
+    r = np.random.default_rng(9000 + seed)
+    n = 6000
+    tex = np.array([[0, *r.uniform(0.2, 1.0, 3), 0, 0, 0], [1, 0.9, 0.9, 0.9, 0.2, 0.5, 0.3], [2, 0, 0, 0, 0, 0, 0]], np.float32)
+    mat = np.array([[1, 0, 0, 0, 0], [2, 1, 0, 0, 0], [1, 2, 0, 0, 0], [1, 1, 0, 0, 0]], np.float32)
+    obj = np.zeros((n + 2, 10), np.float32)
+    c = r.uniform([-60, 0.5, -40], [60, 30, 80], (n, 3))
+    size = r.uniform(0.3, 2.0, n)
+    cube = r.random(n) < 0.3
+    neg = (~cube) & (r.random(n) < 0.2)
+    obj[:n, 0] = np.where(cube, 2, 0)
+    obj[:n, 1:4] = c
+    obj[:n, 4] = np.where(neg, -size, size)
+    obj[:n, 9] = r.choice([0, 1, 3], n)
+    obj[n] = [3, 14.0, 1, 40.0, -8.0, 7.0, 5.0, 1, 0, 2]
+    obj[n + 1] = [3, 9.0, 0, 90.0, 12.0, 5.0, 20.0, 1, 0, 0]
+    args = (tex, mat, obj, [[0.0, 1]], assets["verts"], assets["tex"], assets["sky"], 555 + seed)
+    scene = build_table_scene(rt.Scene(), *args)
+    osc = build_table_scene(orc.Scene(orc.MATH_PORTABLE), *args)
+    assert scene.flat_info()["entries"] > 10000
+    W, H, S, B = 128, 72, 2, 4
+    cam = rt.camera_look((0.0, 15.0, -70.0), (0.0, -0.05, 1.0))
+    ref = osc.render(cam, W, H, S, B, seed, threads=8, want=("radiance", "rgba", "rng_draws", "primary_id", "primary_t"))
+    assert (ref["primary_id"] >= 0).mean() > 0.5
+    E = rt.engine
+    for flags in (0, E.FLAG_NO_PAIRS, E.FLAG_NO_CULL, E.FLAG_NO_ORDER, E.FLAG_NO_REGROUP, E.FLAG_NO_PAIRS | E.FLAG_NO_CULL | E.FLAG_NO_REGROUP):
+        e = make_engine(rt, scene, W, H, S, B, cam, flags=flags)
+        e.keep_samples(True)
+        frame = e.render_frame(seed)
+        got = e.read_samples()
+        for name in ("primary_id", "primary_t", "rng_draws", "radiance"):
+            assert_bits(got[name], ref[name], f"large random scene {seed} (flags {flags}): {name}")
+        assert_bits(frame, ref["rgba"], f"large random scene {seed} (flags {flags}): frame")
+        e.close()
+
+
 @pytest.mark.parametrize("n_tris", [1, 2, 3, 5, 8])
 def test_tiny_meshes(rt, orc, assets, n_tris):
     """meshes of one to eight triangles (a tree that is one lowest node; a root whose children are lowest nodes; the
