@@ -3,7 +3,7 @@
 App.h says `#include "FrameManager.h"` and App.cpp `#include "World.h"` (App.h:2, App.cpp:2): a quoted include looks in
 the including file's own directory first, so the adapter's headers are found only when the reference's engine headers
 (FrameManager.h, World.h, DataUtility.h, Object.h) are NOT beside App.h — putting compat/ in front on the include path
-is not enough.  The test reproduces the layout INTEGRATION.md prescribes in a scratch directory: the four front-end
+is not enough.  The test reproduces the layout a maintainer is told to use in a scratch directory: the four front-end
 files alone, the adapter directory on the include path; it compiles them (syntax and semantics, no code generation —
 there is no SDL2 library for Linux here, its headers ship with the reference) and asks the preprocessor which headers it
 used.  Nothing is copied into the repository."""
@@ -58,7 +58,7 @@ def test_unchanged_front_end_compiles_against_the_adapter(front, unit):
 
 
 def test_beside_the_reference_headers_the_include_path_alone_is_not_enough():
-    """the layout INTEGRATION.md warns about: compiled where it lies, App.cpp finds the reference's FrameManager.h next
+    """the layout a maintainer is warned about: compiled where it lies, App.cpp finds the reference's FrameManager.h next
     to App.h whatever the include path says"""
     deps = gxx(SRC, "-M", "App.cpp")
     assert deps.returncode == 0, deps.stderr[-2000:]
