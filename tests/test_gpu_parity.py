@@ -336,6 +336,44 @@ def test_batching_tiles_and_ranks_do_not_change_pixels(rt, gpu_default):
         assert_bits(out.cpu().numpy().reshape(H, W, 4), base, f"{n_ranks}-rank tile split")
 
 
+def test_batching_tiles_and_ranks_on_a_scene_read_from_memory(rt, orc, assets):
+    """the same properties where the scene is read from memory (four meshes and 61 spheres and cubes, no fog: the engine's own
+    hierarchy, near side first, pair steps) and the camera looks along the z axis without a lens offset, so that the rays of
+    one sample column have d.x = 0 exactly and are handed over to the walk through the reference's hierarchy, in whichever
+    batch or share they fall: small batches, small tiles, windows and rank splits leave every byte unchanged, and the
+    whole frame is the oracle's"""
+    import torch
+    tex, mat, obj, plane, (pos, look) = random_tables(9, fog=False)
+    assert (obj[:, 0] == 3).sum() == 4 and len(obj) == 65
+    args = (tex, mat, obj, plane, assets["verts"], assets["tex"], assets["sky"], 0xABCD)
+    scene = build_table_scene(rt.Scene(), *args)
+    osc = build_table_scene(orc.Scene(orc.MATH_PORTABLE), *args)
+    assert scene.flat_info()["device_bytes"] > 160 * 1024 and scene.regroup_info()["has_regrouped_layout"] == 1
+    W, H, S, B = 200, 120, 2, 4
+    cam = rt.camera_look(pos, (0.0, 0.0, 1.0))
+    kw = dict(dof_intensity=0.0)
+    ref = osc.render(cam, W, H, S, B, 3, dof=0.0, threads=8, want=("rgba",))
+    base = make_engine(rt, scene, W, H, S, B, cam, **kw).render_frame(3)
+    assert_bits(base, ref["rgba"], "frame vs the oracle")
+    assert_bits(make_engine(rt, scene, W, H, S, B, cam, max_batch_paths=9000, **kw).render_frame(3), base, "small batches")
+    assert_bits(make_engine(rt, scene, W, H, S, B, cam, tile_w=16, tile_h=8, max_batch_paths=20000, **kw).render_frame(3), base, "16x8 tiles")
+    e = make_engine(rt, scene, W, H, S, B, cam, **kw)
+    e.set_window((37, 21, 150, 99))
+    win = e.render_frame(3)
+    assert_bits(win[21:99, 37:150], base[21:99, 37:150], "window vs frame")
+    e.set_window(None)
+    for n_ranks in (2, 5):
+        e = make_engine(rt, scene, W, H, S, B, cam, tile_w=32, tile_h=32, max_batch_paths=30000, **kw)
+        nb = e.tile_bytes(n_ranks)
+        gathered = torch.zeros(n_ranks * nb, dtype=torch.uint8, device="cuda")
+        for r in range(n_ranks):
+            e.render(3, rank=r, n_ranks=n_ranks, d_out=gathered.data_ptr() + r * nb)
+        out = torch.zeros(H * W * 4, dtype=torch.uint8, device="cuda")
+        e.assemble(gathered.data_ptr(), n_ranks, d_out=out.data_ptr())
+        e.sync()
+        assert_bits(out.cpu().numpy().reshape(H, W, 4), base, f"{n_ranks}-rank tile split")
+
+
 def test_c2_full_frame_properties(rt, gpu_default, monkeypatch):
     """BASELINE's full size (1920x1080, 64 spp, 8 bounces): deterministic, alpha constant, windows agree with the frame"""
     W, H, S, B = 1920, 1080, 8, 8
