@@ -75,6 +75,10 @@ typedef struct rt_config {
  * child to visit first chosen by the split axis — the same results through the other variant of the kernel, for
  * comparisons and tests. */
 #define RT_FLAG_NO_PAIRS 16
+/* In a scene held in on-chip memory a node of the engine's own hierarchy may list more than two children: a box that
+ * nearly fills its parent's is left out and its children are tested in its place (fewer box tests, the same leaves).
+ * This flag keeps every node at two children — for comparisons and tests. */
+#define RT_FLAG_NO_WIDE 32
 void rt_config_defaults(rt_config* cfg);   /* the values of Constants.h:4-17 */
 
 /* ---------------------------------------------------------------------------------------------------------
@@ -134,7 +138,10 @@ int rt_scene_flat_info(const rt_scene* s, int64_t out7[7]);
  * a random line through the top-level tree and through the meshes' trees in the reference's layout, the same two in the
  * regrouped layout, stack slots the ordered traversal needs there }; no counterpart in the reference */
 int rt_scene_regroup_info(const rt_scene* s, double out8[8]);
-/* the flattened entries of the reference's layout (regrouped = 0) or the regrouped one: 8 floats per entry (box minimum or
+/* the regrouped layout with wide nodes (RT_FLAG_NO_WIDE): out4 = { has one, entries, expected slab tests of a random line
+ * through the meshes' trees, most children under one node }; no counterpart in the reference */
+int rt_scene_wide_info(const rt_scene* s, double out4[4]);
+/* the flattened entries of the reference's layout (regrouped = 0), the regrouped one (1) or the one with wide nodes (2): 8 floats per entry (box minimum or
  * leaf data, link; box maximum, kind — integers as bit patterns), the same leaf's entry in the other layout (-1: none) and
  * a leaf's rank in the reference's visiting order; returns the number of entries (all arrays null: only that) */
 int rt_scene_dump_entries(const rt_scene* s, int regrouped, int max_entries, float* lo_hi8, int32_t* peer, uint32_t* rank);

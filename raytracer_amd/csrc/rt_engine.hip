@@ -1111,13 +1111,13 @@ int rt_engine_get_config(const rt_engine* e, rt_config* out) {
 // free (sphere, cube: dword 7; triangle: dword 0; a fog volume has none, and scenes with fog need none): its rank in the
 // reference's visiting order (what settles equal distances), or, in the reference's layout when the engine renders from
 // the regrouped one, the leaf's entry there (`leaf_peer`: what the walk of an exceptional ray reports).
-static std::vector<rt::F4> device_entries(const rt_layout& L, bool leaf_peer, bool& has_fog) {
+static std::vector<rt::F4> device_entries(const rt_layout& L, const std::vector<int32_t>* leaf_peer, bool& has_fog) {
     std::vector<rt::F4> inter(L.ent_lo.size() * 2);
     for (size_t i = 0; i < L.ent_lo.size(); i++) {
         const rt::F4 lo = L.ent_lo[i], hi = L.ent_hi[i];
         const int kind = rt::bits_i(hi.w);
         auto tag = [](int k, int payload) { return rt::bits_f((int32_t)(((uint32_t)k << rt::SK_SHIFT) | (uint32_t)payload)); };
-        const float extra = rt::bits_f(leaf_peer ? L.ent_peer[i] : (int32_t)L.ent_rank[i]);
+        const float extra = rt::bits_f(leaf_peer ? (*leaf_peer)[i] : (int32_t)L.ent_rank[i]);
         rt::F4 a{0, 0, 0, 0}, b{0, 0, tag(kind, 0), 0};
         switch (kind) {
         case rt::ENT_INNER:
@@ -1177,7 +1177,10 @@ static int rt_engine_set_scene_impl(rt_engine* e, const rt_scene* s) {
     free_scene(e);
     // the layout the kernels walk: the regrouped one when the scene has it, else the reference's
     const bool use_fast = f->has_fast && !(e->cfg.flags & RT_FLAG_NO_REGROUP);
-    const rt_layout& L = use_fast ? f->fast : static_cast<const rt_layout&>(*f);
+    // ... with wide nodes when the scene will be held on chip (the kernels that read it from memory walk pairs of children)
+    auto staged_need = [&](const rt_layout& X) { return (2 * X.ent_lo.size() + f->tris.size() + X.inst.size() + f->planes.size()) * 16; };
+    const bool use_wide = use_fast && f->has_wide && !(e->cfg.flags & (RT_FLAG_NO_LDS | RT_FLAG_NO_WIDE)) && staged_need(f->wide) <= (size_t)MAX_STAGED_BYTES;
+    const rt_layout& L = use_wide ? f->wide : use_fast ? f->fast : static_cast<const rt_layout&>(*f);
     Scene sc{};
     float4 *ent, *tris, *inst, *objects, *planes;
     rt::ImageRec* images;
@@ -1187,7 +1190,7 @@ static int rt_engine_set_scene_impl(rt_engine* e, const rt_scene* s) {
     // (a bounce records where its colour is in 29 bits: an object id, or a texel's byte offset / 4)
     if (f->texels.size() >= ((size_t)1 << 31)) return fail(RT_E_INVALID, "scene too large: 2 GiB of texels or more");
     bool has_fog = false;
-    std::vector<rt::F4> inter = device_entries(L, false, has_fog);
+    std::vector<rt::F4> inter = device_entries(L, nullptr, has_fog);
     if (int rc = upload(&ent, inter.data(), inter.size() * 16)) return rc;
     e->scene_allocs.push_back(ent);
     // device triangles carry the two edges Triangle::Intersect starts from (Object.cpp:503-504: the same float
@@ -1253,7 +1256,7 @@ static int rt_engine_set_scene_impl(rt_engine* e, const rt_scene* s) {
     e->sc_ref = Scene{};
     if (use_fast) {
         bool fog_ref = false;
-        std::vector<rt::F4> inter_ref = device_entries(*f, true, fog_ref);
+        std::vector<rt::F4> inter_ref = device_entries(*f, use_wide ? &f->ent_peer_wide : &f->ent_peer, fog_ref);
         std::vector<rt::F4> inst_ref;
         if (int rc = device_instances(*f, f, alpha_at, inst_ref)) return rc;
         float4 *d_ent_ref, *d_inst_ref;

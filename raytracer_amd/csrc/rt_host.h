@@ -98,6 +98,13 @@ struct rt_scene_flat : rt_layout {
     bool has_fast = false;                   // `fast` is filled: some tree of the scene was regrouped
     rt_layout fast;
     int32_t regrouped_trees = 0, regrouped_groups = 0;
+    // The regrouped layout once more, for the kernels that hold the scene on chip and walk it by skip links alone: an
+    // inner node of a rebuilt hierarchy whose box is more than half of its parent's (by surface) is left out and its
+    // children are listed under the parent (rt_scene.cpp, "wide nodes").  ent_peer_wide: by entry of the reference's
+    // layout, the same leaf's entry here.
+    bool has_wide = false;
+    rt_layout wide;
+    std::vector<int32_t> ent_peer_wide;
 };
 
 const rt_scene_flat* rt_scene_get_flat(const struct rt_scene* s);

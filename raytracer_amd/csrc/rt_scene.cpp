@@ -458,6 +458,7 @@ struct Flattener {
     std::vector<int>& tri_of;       // by object index: the triangle's record, -1 until it has one
     std::vector<int>& ent_obj;      // by entry of this layout: the object of a leaf or instance entry, -1 for other entries
     bool regroup = false;           // rebuild the upper levels of the trees that allow it
+    double collapse = 0;            // > 0: wide nodes (see emit_regrouped)
     double entry_margin = -1;       // >= 0: mesh instances get an entry box (see entry_box) widened by this much
     int regrouped_trees = 0, regrouped_groups = 0;
     int first_leaf = -1;            // first leaf entry of the list being emitted
@@ -551,10 +552,36 @@ struct Flattener {
         const bool a_first = ba.mn[axis] <= bb.mn[axis];
         const int at = (int)f.ent_lo.size();
         push({n.box.mn.x, n.box.mn.y, n.box.mn.z, 0}, {n.box.mx.x, n.box.mx.y, n.box.mx.z, bits_f(ENT_INNER)}, -1);
+        if (collapse > 0) {
+            int right_at = -1, listed = 0;
+            emit_children(rg, child, n.box, top_level, right_at, listed);
+            note_children(at, right_at, axis);
+            return;
+        }
         emit_regrouped(rg, a_first ? n.a : n.b, top_level);
         const int right_at = (int)f.ent_lo.size();
         emit_regrouped(rg, a_first ? n.b : n.a, top_level);
         note_children(at, right_at, axis);
+    }
+    // Wide nodes.  A walk that follows skip links tests the box of every child of a node whose box is hit.  An inner child
+    // is worth its own test only if the test often fails: with p the chance that a ray through the parent's box meets the
+    // child's (the ratio of their surfaces), listing the child costs 1 + 2p tests, listing its two children in its place
+    // costs 2 — less when p > 1/2.  So the children of `child` are listed under the box `parent`, and an inner child
+    // with more than `collapse` of the parent's surface is replaced by its own children, measured against the same
+    // parent.  Every box that remains is a union of lowest nodes' boxes inside its parent's, which is all the walk's
+    // exactness rests on ("regrouping").  (Not for the ordered traversal, whose entries name exactly two children.)
+    static double area_of(const Box3& b) {
+        const double x = (double)b.mx.x - b.mn.x, y = (double)b.mx.y - b.mn.y, z = (double)b.mx.z - b.mn.z;
+        return x * y + y * z + x * z;
+    }
+    void emit_children(const Regroup& rg, int child, const Box3& parent, bool top_level, int& right_at, int& listed) {
+        const Regroup::FNode& n = rg.nodes[(size_t)child];
+        for (int c : {n.a, n.b}) {
+            if (c >= 0 && area_of(rg.nodes[(size_t)c].box) > collapse * area_of(parent)) { emit_children(rg, c, parent, top_level, right_at, listed); continue; }
+            if (listed == 1) right_at = (int)f.ent_lo.size();
+            listed++;
+            emit_regrouped(rg, c, top_level);
+        }
     }
     // One tree of the scene: the top-level tree or a mesh's.  Only meshes are regrouped.  The top-level tree of a large
     // scene is walked near side first with distance culling, and there the reference's own upper levels do better than
@@ -585,11 +612,12 @@ struct Flattener {
 // One layout of the scene: entries, instance records, what the ordered traversal and distance culling need per entry.
 // inst_obj: by instance of this layout, the object (wrapper chain) it stands for.
 void flatten_layout(const rt_scene& s, rt_layout& f, std::vector<F4>& tris, std::vector<int>& tri_of, std::vector<int>& ent_obj,
-                    std::vector<int>& inst_obj, bool regroup, double entry_margin, int* regrouped_trees, int* regrouped_groups) {
+                    std::vector<int>& inst_obj, bool regroup, double entry_margin, int* regrouped_trees, int* regrouped_groups, double collapse = 0) {
     f = rt_layout();
     ent_obj.clear();
     Flattener fl{s, f, tris, tri_of, ent_obj};
     fl.regroup = regroup;
+    fl.collapse = collapse;
     fl.entry_margin = entry_margin;
     fl.emit_tree(s.root, true);
     f.top_end = (int)f.ent_lo.size();
@@ -612,6 +640,7 @@ void flatten_layout(const rt_scene& s, rt_layout& f, std::vector<F4>& tris, std:
         const int begin = (int)f.ent_lo.size();
         Flattener sub{s, f, tris, tri_of, ent_obj};
         sub.regroup = regroup;
+        sub.collapse = collapse;
         if (s.objs[idx].kind == MESH) sub.emit_tree(s.objs[idx].root, false);
         else sub.emit_leaf(idx, false);   // a wrapped fog volume: a range of one entry
         trees += sub.regrouped_trees; groups += sub.regrouped_groups;
@@ -741,27 +770,38 @@ void flatten(rt_scene& s) {
     f.cull_delta = (c_max + 2.0f * r_max) * 1.1920928955078125e-07f;             // 2^-23 (max |c| + r) + 2^-22 r_max
     // The regrouped layout (see "regrouping"); never with fog, whose random draws follow the reference's visiting order
     if (f.fast_div_ok && !has_fog && !getenv("RT_NO_REGROUP")) {
+        // leaves of a layout of the engine's own and of the reference's name each other; ranks and the leaves whose
+        // rejected HitInfo.distance survives (the reference's first leaves, wherever they stand now) go with them
+        auto tie = [&](rt_layout& own, const std::vector<int>& ent_obj_own, const std::vector<int>& inst_obj_own, std::vector<int32_t>& peer_of_ref) {
+            std::vector<int> at_own(s.objs.size(), -1);
+            for (size_t e = 0; e < ent_obj_own.size(); e++) if (ent_obj_own[e] >= 0) at_own[(size_t)ent_obj_own[e]] = (int)e;
+            peer_of_ref.assign(f.ent_lo.size(), -1);
+            for (size_t e = 0; e < ent_obj.size(); e++) {
+                if (ent_obj[e] < 0) continue;
+                const int fe = at_own[(size_t)ent_obj[e]];
+                peer_of_ref[e] = fe;
+                own.ent_peer[(size_t)fe] = (int)e;
+                own.ent_rank[(size_t)fe] = f.ent_rank[e];
+            }
+            own.stale_entry = f.stale_entry >= 0 ? peer_of_ref[(size_t)f.stale_entry] : -1;
+            for (size_t kf = 0; kf < inst_obj_own.size(); kf++)
+                for (size_t kr = 0; kr < inst_obj.size(); kr++)
+                    if (inst_obj[kr] == inst_obj_own[kf]) {
+                        const int first = bits_i(f.inst[kr * RT_INST_F4 + 3].y);
+                        own.inst[kf * RT_INST_F4 + 3].y = bits_f(first >= 0 ? peer_of_ref[(size_t)first] : -1);
+                    }
+        };
         std::vector<int> ent_obj_fast, inst_obj_fast;
         flatten_layout(s, f.fast, f.tris, tri_of, ent_obj_fast, inst_obj_fast, true, entry_margin, &f.regrouped_trees, &f.regrouped_groups);
         if (f.regrouped_trees > 0) {
             f.has_fast = true;
-            std::vector<int> at_fast(s.objs.size(), -1);
-            for (size_t e = 0; e < ent_obj_fast.size(); e++) if (ent_obj_fast[e] >= 0) at_fast[(size_t)ent_obj_fast[e]] = (int)e;
-            for (size_t e = 0; e < ent_obj.size(); e++) {
-                if (ent_obj[e] < 0) continue;
-                const int fe = at_fast[(size_t)ent_obj[e]];
-                f.ent_peer[e] = fe;
-                f.fast.ent_peer[(size_t)fe] = (int)e;
-                f.fast.ent_rank[(size_t)fe] = f.ent_rank[e];
+            tie(f.fast, ent_obj_fast, inst_obj_fast, f.ent_peer);
+            if (!getenv("RT_NO_WIDE")) {
+                std::vector<int> ent_obj_wide, inst_obj_wide;
+                flatten_layout(s, f.wide, f.tris, tri_of, ent_obj_wide, inst_obj_wide, true, entry_margin, nullptr, nullptr, 0.5);
+                f.has_wide = true;
+                tie(f.wide, ent_obj_wide, inst_obj_wide, f.ent_peer_wide);
             }
-            // the leaves whose rejected HitInfo.distance survives are the reference's first leaves, wherever they stand now
-            f.fast.stale_entry = f.stale_entry >= 0 ? f.ent_peer[(size_t)f.stale_entry] : -1;
-            for (size_t kf = 0; kf < inst_obj_fast.size(); kf++)
-                for (size_t kr = 0; kr < inst_obj.size(); kr++)
-                    if (inst_obj[kr] == inst_obj_fast[kf]) {
-                        const int first = bits_i(f.inst[kr * RT_INST_F4 + 3].y);
-                        f.fast.inst[kf * RT_INST_F4 + 3].y = bits_f(first >= 0 ? f.ent_peer[(size_t)first] : -1);
-                    }
         } else f.fast = rt_layout();
     }
     // texel pool: images, then the skybox; each padded by one zero row because uv == 1.0 indexes row h
@@ -1211,7 +1251,8 @@ int rt_scene_dump_entries(const rt_scene* s, int regrouped, int max_entries, flo
     if (!s || !s->built) return fail(RT_E_INVALID, "scene is not built");
     const rt_scene_flat& f = s->flat;
     if (regrouped && !f.has_fast) return fail(RT_E_INVALID, "the scene has no regrouped layout");
-    const rt_layout& L = regrouped ? f.fast : static_cast<const rt_layout&>(f);
+    if (regrouped == 2 && !f.has_wide) return fail(RT_E_INVALID, "the scene has no layout with wide nodes");
+    const rt_layout& L = regrouped == 2 ? f.wide : regrouped ? f.fast : static_cast<const rt_layout&>(f);
     const int n = (int)L.ent_lo.size();
     if (!lo_hi8 && !peer && !rank) return n;
     if (n > max_entries) return fail(RT_E_INVALID, "entry buffer too small");
@@ -1235,6 +1276,23 @@ int rt_scene_regroup_info(const rt_scene* s, double out[8]) {
         out[5] = expected_box_tests(f.fast, 0, f.fast.top_end);
         for (size_t k = 0; k + RT_INST_F4 <= f.fast.inst.size(); k += RT_INST_F4) out[6] += expected_box_tests(f.fast, bits_i(f.fast.inst[k + 2].z), bits_i(f.fast.inst[k + 2].w));
         out[7] = f.fast.stack_need;
+    }
+    return RT_OK;
+}
+
+int rt_scene_wide_info(const rt_scene* s, double out[4]) {
+    if (!s || !s->built || !out) return fail(RT_E_INVALID, "scene is not built");
+    const rt_scene_flat& f = s->flat;
+    for (int k = 0; k < 4; k++) out[k] = 0;
+    if (!f.has_wide) return RT_OK;
+    out[0] = 1;
+    out[1] = (double)f.wide.ent_lo.size();
+    for (size_t k = 0; k + RT_INST_F4 <= f.wide.inst.size(); k += RT_INST_F4) out[2] += expected_box_tests(f.wide, bits_i(f.wide.inst[k + 2].z), bits_i(f.wide.inst[k + 2].w));
+    for (size_t i = 0; i < f.wide.ent_lo.size(); i++) {
+        if (bits_i(f.wide.ent_hi[i].w) != ENT_INNER) continue;
+        int kids = 0;
+        for (int c = (int)i + 1; c < bits_i(f.wide.ent_lo[i].w); c = bits_i(f.wide.ent_hi[c].w) == ENT_INNER ? bits_i(f.wide.ent_lo[c].w) : c + 1) kids++;
+        out[3] = std::max(out[3], (double)kids);
     }
     return RT_OK;
 }

@@ -21,6 +21,7 @@ FLAG_NO_LDS = 2                 # RT_FLAG_NO_LDS
 FLAG_NO_ORDER = 4               # RT_FLAG_NO_ORDER
 FLAG_NO_REGROUP = 8             # RT_FLAG_NO_REGROUP
 FLAG_NO_PAIRS = 16              # RT_FLAG_NO_PAIRS
+FLAG_NO_WIDE = 32               # RT_FLAG_NO_WIDE
 
 f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
@@ -78,6 +79,7 @@ SIGNATURES = {
     "rt_scene_dump_instance": (C.c_int, [_V, C.c_int, f32p]),
     "rt_scene_flat_info": (C.c_int, [_V, i64p]),
     "rt_scene_regroup_info": (C.c_int, [_V, f64p]),
+    "rt_scene_wide_info": (C.c_int, [_V, f64p]),
     "rt_scene_dump_entries": (C.c_int, [_V, C.c_int, C.c_int, _V, _V, _V]),
     "rt_load_obj": (C.c_int, [C.c_char_p, C.c_int, _V]),
     "rt_load_png": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int64, _V, i32p, i32p, i32p]),
@@ -310,13 +312,19 @@ class Scene:
         return out
 
     def dump_entries(self, regrouped=False):
-        """(lo_hi [n, 8] float32, peer [n] int32, rank [n] uint32) of the reference's layout or the regrouped one"""
+        """(lo_hi [n, 8] float32, peer [n] int32, rank [n] uint32) of the reference's layout, the regrouped one (True / 1) or
+        the regrouped one with wide nodes (2)"""
         n = _check(self.L.rt_scene_dump_entries(self.h, int(regrouped), 0, None, None, None))
         e = np.zeros((n, 8), np.float32)
         peer = np.zeros(n, np.int32)
         rank = np.zeros(n, np.uint32)
         _check(self.L.rt_scene_dump_entries(self.h, int(regrouped), n, _ptr(e), _ptr(peer), _ptr(rank)))
         return e, peer, rank
+
+    def wide_info(self):
+        out = np.zeros(4, np.float64)
+        _check(self.L.rt_scene_wide_info(self.h, out))
+        return dict(zip(("has_wide_layout", "entries", "mesh_tests_wide", "most_children"), (float(v) for v in out)))
 
     def regroup_info(self):
         out = np.zeros(8, np.float64)

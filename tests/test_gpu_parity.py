@@ -702,7 +702,7 @@ def test_rays_the_regrouped_hierarchy_is_not_proven_for(rt, oracle_default, gpu_
     assert_bits(col, oracle_default.ray_color(o, d, 4, keys), "radiance of such rays vs the oracle")
     assert_bits(col, e0.ray_color(o, d, 4, keys), "radiance vs the engine on the reference's hierarchy")
     # the same through the kernels that read the scene from memory (near side first: pair steps, one box per step)
-    for flags in (rt.engine.FLAG_NO_LDS, rt.engine.FLAG_NO_LDS | rt.engine.FLAG_NO_PAIRS, rt.engine.FLAG_NO_LDS | rt.engine.FLAG_NO_ORDER):
+    for flags in (rt.engine.FLAG_NO_LDS, rt.engine.FLAG_NO_LDS | rt.engine.FLAG_NO_PAIRS, rt.engine.FLAG_NO_LDS | rt.engine.FLAG_NO_ORDER, rt.engine.FLAG_NO_WIDE):
         em = make_engine(rt, gpu_default, 128, 128, 1, 4, flags=flags)
         assert_bits(em.ray_color(o, d, 4, keys), col, f"radiance of such rays, scene read from memory (flags {flags})")
         em.close()
@@ -777,7 +777,7 @@ def test_rays_outside_the_fast_paths(rt, orc, assets):
     assert (h_or >= 0).sum() > 500 and (h_or[:3 * k] == 0).sum() > 50        # far rays do meet the tree
     cam = rt.camera_look(CAM_POS, CAM_LOOK)
     E = rt.engine
-    for flags in (0, E.FLAG_NO_REGROUP, E.FLAG_NO_LDS, E.FLAG_NO_LDS | E.FLAG_NO_PAIRS, E.FLAG_NO_LDS | E.FLAG_NO_REGROUP, E.FLAG_NO_LDS | E.FLAG_NO_ORDER):
+    for flags in (0, E.FLAG_NO_WIDE, E.FLAG_NO_REGROUP, E.FLAG_NO_LDS, E.FLAG_NO_LDS | E.FLAG_NO_PAIRS, E.FLAG_NO_LDS | E.FLAG_NO_REGROUP, E.FLAG_NO_LDS | E.FLAG_NO_ORDER):
         e = make_engine(rt, scene, 64, 64, 1, 3, cam, flags=flags)
         hit, rec = e.trace(o, d)
         assert_bits(hit, h_or, f"ids of rays outside the fast paths (flags {flags})")
@@ -899,7 +899,7 @@ def _random_scene_check(rt, orc, assets, seed, monkeypatch, fog):
     # (FLAG_NO_PAIRS: one box per step of the near-side-first walk instead of a node's two children per step)
     for flags in (E.FLAG_NO_LDS, E.FLAG_NO_LDS | E.FLAG_NO_CULL, E.FLAG_NO_LDS | E.FLAG_NO_ORDER, E.FLAG_NO_LDS | E.FLAG_NO_ORDER | E.FLAG_NO_CULL, 0,
                   E.FLAG_NO_REGROUP, E.FLAG_NO_REGROUP | E.FLAG_NO_LDS, E.FLAG_NO_LDS | E.FLAG_NO_PAIRS, E.FLAG_NO_LDS | E.FLAG_NO_PAIRS | E.FLAG_NO_CULL,
-                  E.FLAG_NO_LDS | E.FLAG_NO_PAIRS | E.FLAG_NO_REGROUP):
+                  E.FLAG_NO_LDS | E.FLAG_NO_PAIRS | E.FLAG_NO_REGROUP, E.FLAG_NO_WIDE):    # (FLAG_NO_WIDE: on chip, two children per node throughout)
         m = make_engine(rt, scene, W, H, S, B, cam, flags=flags)
         m.keep_samples(True)
         frame_m = m.render_frame(seed)
@@ -981,7 +981,7 @@ def test_tiny_meshes(rt, orc, assets, n_tris):
     ref = osc.render(cam, W, H, S, B, 5, threads=8, want=("radiance", "rgba", "rng_draws", "primary_id", "primary_t"))
     assert ((ref["primary_id"] == 0) | (ref["primary_id"] == 1)).mean() > 0.002         # the meshes are in view
     E = rt.engine
-    for flags in (0, E.FLAG_NO_REGROUP, E.FLAG_NO_LDS, E.FLAG_NO_LDS | E.FLAG_NO_PAIRS, E.FLAG_NO_LDS | E.FLAG_NO_ORDER, E.FLAG_NO_LDS | E.FLAG_NO_CULL,
+    for flags in (0, E.FLAG_NO_WIDE, E.FLAG_NO_REGROUP, E.FLAG_NO_LDS, E.FLAG_NO_LDS | E.FLAG_NO_PAIRS, E.FLAG_NO_LDS | E.FLAG_NO_ORDER, E.FLAG_NO_LDS | E.FLAG_NO_CULL,
                   E.FLAG_NO_LDS | E.FLAG_NO_REGROUP, E.FLAG_NO_LDS | E.FLAG_NO_REGROUP | E.FLAG_NO_PAIRS):
         e = make_engine(rt, scene, W, H, S, B, cam, flags=flags)
         e.keep_samples(True)

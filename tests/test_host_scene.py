@@ -218,12 +218,15 @@ def test_c3_tree_built_by_the_product(rt, golden, assets):
     print(f"C3 scene through the C ABI: {dt:.2f} s including {int(g['n'])} object and material calls from Python")
 
 
+@pytest.mark.parametrize("layout", [1, 2])
 @pytest.mark.parametrize("key", [0x12345678, 0x5EED0001, 7])
-def test_regrouped_layout_keeps_the_lowest_nodes_and_their_leaves(rt, key):
+def test_regrouped_layout_keeps_the_lowest_nodes_and_their_leaves(rt, key, layout):
     """The regrouped layout (the levels of a mesh's tree above its lowest nodes rebuilt): every leaf and every lowest node
     of the reference's layout is there with the same bits, leaves keep their ranks, every box of the new upper levels
     contains the boxes below it (which is what makes it visit every lowest node the reference visits), and the top-level
-    tree — whose boxes over negative radii are not even ordered — is left alone."""
+    tree — whose boxes over negative radii are not even ordered — is left alone.  layout 2: the same with wide nodes (a
+    box of more than half its parent's surface left out, its children listed in its place): fewer entries, nodes of up to
+    six children, and by the surface measure fewer tests again."""
     ENT_INNER, ENT_TRI, ENT_INSTANCE = 0, 3, 8
     s = rt.default_scene(key)
     info = s.regroup_info()
@@ -231,13 +234,23 @@ def test_regrouped_layout_keeps_the_lowest_nodes_and_their_leaves(rt, key):
     assert info["mesh_tests_regrouped"] < 0.8 * info["mesh_tests_reference"], info
     assert info["top_tests_regrouped"] == info["top_tests_reference"]
     ref, ref_peer, ref_rank = s.dump_entries(False)
-    new, new_peer, new_rank = s.dump_entries(True)
-    assert len(ref) == len(new)                                        # a binary tree over the same lowest nodes
+    new, new_peer, new_rank = s.dump_entries(layout)
+    if layout == 1:
+        assert len(ref) == len(new)                                    # a binary tree over the same lowest nodes
+    else:
+        wide = s.wide_info()
+        assert wide["has_wide_layout"] == 1 and wide["entries"] == len(new) < len(ref) - 100
+        assert 3 <= wide["most_children"] <= 8 and wide["mesh_tests_wide"] < 0.95 * info["mesh_tests_regrouped"]
     kind = lambda e: e[:, 7].view(np.int32)
     link = lambda e: e[:, 3].view(np.int32)
     leaf_r = np.nonzero((kind(ref) >= 1) & (kind(ref) <= 4))[0]
     leaf_n = np.nonzero((kind(new) >= 1) & (kind(new) <= 4))[0]
     assert len(leaf_r) == len(leaf_n) and (kind(ref) == ENT_TRI).sum() == 457
+    if layout == 2:
+        # (a leaf of the reference's layout names its entry in the regrouped layout without wide nodes; the way from there
+        # to this layout is this layout's own peers, read backwards)
+        ref_peer = np.full(len(ref), -1, np.int32)
+        ref_peer[new_peer[leaf_n]] = leaf_n
     # leaves: same data, same rank, peers point at each other; ranks number the leaves in the reference's order
     assert sorted(ref_peer[leaf_r].tolist()) == leaf_n.tolist()
     assert (new_peer[ref_peer[leaf_r]] == leaf_r).all()
@@ -274,4 +287,4 @@ def test_regrouped_layout_keeps_the_lowest_nodes_and_their_leaves(rt, key):
                 c = ln[c]
             else:
                 c += 1
-    assert checked >= 500
+    assert checked >= (500 if layout == 1 else 350)
