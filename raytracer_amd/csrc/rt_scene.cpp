@@ -459,6 +459,7 @@ struct Flattener {
     std::vector<int>& ent_obj;      // by entry of this layout: the object of a leaf or instance entry, -1 for other entries
     bool regroup = false;           // rebuild the upper levels of the trees that allow it
     double collapse = 0;            // > 0: wide nodes (see emit_regrouped)
+    bool behind_entry_box = false;  // the tree is a mesh instance's and the instance has an entry box (see emit_tree)
     double entry_margin = -1;       // >= 0: mesh instances get an entry box (see entry_box) widened by this much
     int regrouped_trees = 0, regrouped_groups = 0;
     int first_leaf = -1;            // first leaf entry of the list being emitted
@@ -596,7 +597,13 @@ struct Flattener {
             if (rg.build(root)) {
                 regrouped_trees++;
                 regrouped_groups += (int)rg.groups.size();
-                emit_regrouped(rg, rg.root, top_level);
+                // With wide nodes the root of a mesh behind an entry box is the first node to be left out: a ray comes
+                // here through the entry box, which is the root's box taken to the scene's frame and widened, so the
+                // root's own test hardly ever fails; its children start the instance's list.
+                if (collapse > 0 && behind_entry_box && !top_level && rg.root >= 0) {
+                    int right_at = -1, listed = 0;
+                    emit_children(rg, rg.root, rg.nodes[(size_t)rg.root].box, top_level, right_at, listed);
+                } else emit_regrouped(rg, rg.root, top_level);
                 return;
             }
         }
@@ -641,6 +648,7 @@ void flatten_layout(const rt_scene& s, rt_layout& f, std::vector<F4>& tris, std:
         Flattener sub{s, f, tris, tri_of, ent_obj};
         sub.regroup = regroup;
         sub.collapse = collapse;
+        { double wb[6]; sub.behind_entry_box = entry_margin >= 0 && entry_box(s, fl.pending[k], wb); }
         if (s.objs[idx].kind == MESH) sub.emit_tree(s.objs[idx].root, false);
         else sub.emit_leaf(idx, false);   // a wrapped fog volume: a range of one entry
         trees += sub.regrouped_trees; groups += sub.regrouped_groups;
@@ -1232,9 +1240,16 @@ static double expected_box_tests(const rt_layout& L, int begin, int end) {
         return x * y + y * z + x * z;
     };
     if (begin >= end || bits_i(L.ent_hi[begin].w) != ENT_INNER) return 0.0;
-    const double root = area(begin);
+    // (the range is a list of siblings — one root, or a left-out root's children: the line goes through the box around them)
+    double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY}, sum = 0.0;
+    for (int c = begin; c < end; c = bits_i(L.ent_hi[c].w) == ENT_INNER ? bits_i(L.ent_lo[c].w) : c + 1) {
+        if (bits_i(L.ent_hi[c].w) != ENT_INNER) continue;
+        sum += 1.0;
+        const float mn[3] = {L.ent_lo[c].x, L.ent_lo[c].y, L.ent_lo[c].z}, mx[3] = {L.ent_hi[c].x, L.ent_hi[c].y, L.ent_hi[c].z};
+        for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], (double)mn[k]); hi[k] = std::max(hi[k], (double)mx[k]); }
+    }
+    const double root = (hi[0] - lo[0]) * (hi[1] - lo[1]) + (hi[1] - lo[1]) * (hi[2] - lo[2]) + (hi[0] - lo[0]) * (hi[2] - lo[2]);
     if (!(root > 0)) return 0.0;
-    double sum = 1.0;
     for (int i = begin; i < end; i++) {
         if (bits_i(L.ent_hi[i].w) != ENT_INNER) continue;
         const int skip = bits_i(L.ent_lo[i].w);
